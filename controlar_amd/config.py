@@ -1,0 +1,126 @@
+"""Model/shape configuration for the ControlAR conditional-decoding hot path.
+
+Mirrors the reference's hyper-parameter dataclasses for the components on the path
+(reference: autoregressive/models/gpt_t2i.py:31-60 ModelArgs, :556-563 GPT_XL/GPT_B;
+tokenizer/tokenizer_image/vq_model.py:12-24 ModelArgs, :422 VQ_16; HF Dinov2Config as
+instantiated by autoregressive/models/dinov2_adapter.py:13).  Nothing here computes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, asdict
+from typing import List, Tuple
+
+
+def find_multiple(n: int, k: int) -> int:
+    """reference: autoregressive/models/gpt_t2i.py:26-29"""
+    return n if n % k == 0 else n + k - (n % k)
+
+
+def ffn_hidden_dim(dim: int, multiple_of: int = 256) -> int:
+    """reference: autoregressive/models/gpt_t2i.py:204-209 (FeedForward.__init__)"""
+    hidden = int(2 * (4 * dim) / 3)
+    return find_multiple(hidden, multiple_of)
+
+
+@dataclass
+class GPTConfig:
+    dim: int = 1280
+    n_layer: int = 36
+    n_head: int = 20
+    vocab_size: int = 16384
+    cls_token_num: int = 120          # text prefix length T (t2i)
+    block_size: int = 1024            # image tokens; rope grid = sqrt(block_size)
+    caption_dim: int = 2048
+    norm_eps: float = 1e-5
+    rope_base: float = 10000.0
+    multiple_of: int = 256
+    model_type: str = "t2i"
+    num_classes: int = 1000
+    adapter_size: str = "small"
+    condition_type: str = "canny"
+
+    @property
+    def head_dim(self) -> int:
+        return self.dim // self.n_head
+
+    @property
+    def ffn_hidden(self) -> int:
+        return ffn_hidden_dim(self.dim, self.multiple_of)
+
+    @property
+    def grid(self) -> int:
+        g = int(self.block_size ** 0.5)
+        assert g * g == self.block_size
+        return g
+
+    @property
+    def layer_internal(self) -> int:
+        return self.n_layer // 3
+
+
+@dataclass
+class ViTConfig:
+    """DINOv2 encoder as the reference instantiates it."""
+    hidden: int = 384
+    layers: int = 12
+    heads: int = 6
+    mlp_ratio: int = 4
+    patch: int = 14
+    image_size: int = 518             # native pos-emb grid = image_size // patch = 37
+    ln_eps: float = 1e-6
+
+    @property
+    def mlp(self) -> int:
+        return self.hidden * self.mlp_ratio
+
+    @property
+    def pos_grid(self) -> int:
+        return self.image_size // self.patch
+
+
+@dataclass
+class VQConfig:
+    codebook_size: int = 16384
+    codebook_embed_dim: int = 8
+    z_channels: int = 256
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 1, 2, 2, 4)
+    num_res_blocks: int = 2
+    gn_groups: int = 32
+    gn_eps: float = 1e-6
+
+
+@dataclass
+class PathConfig:
+    gpt: GPTConfig = field(default_factory=GPTConfig)
+    vit: ViTConfig = field(default_factory=ViTConfig)
+    vq: VQConfig = field(default_factory=VQConfig)
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def xl_t2i(block_size: int = 1024, adapter_size: str = "small", condition_type: str = "canny") -> PathConfig:
+    """BASELINE configs 2-5: GPT-XL t2i (reference: gpt_t2i.py:556, sample_t2i.py:56-62)."""
+    vit = ViTConfig() if adapter_size == "small" else ViTConfig(hidden=768, heads=12)
+    return PathConfig(gpt=GPTConfig(block_size=block_size, adapter_size=adapter_size,
+                                    condition_type=condition_type), vit=vit, vq=VQConfig())
+
+
+def b_t2i(block_size: int = 256, adapter_size: str = "small", condition_type: str = "canny") -> PathConfig:
+    """GPT-B sized t2i (reference: gpt_t2i.py:562)."""
+    vit = ViTConfig() if adapter_size == "small" else ViTConfig(hidden=768, heads=12)
+    return PathConfig(gpt=GPTConfig(dim=768, n_layer=12, n_head=12, block_size=block_size,
+                                    adapter_size=adapter_size, condition_type=condition_type),
+                      vit=vit, vq=VQConfig())
+
+
+def tiny_t2i(block_size: int = 64, condition_type: str = "canny", vocab_size: int = 1024) -> PathConfig:
+    """Small parity-test configuration: same graph, every dimension shrunk so the CPU oracle
+    (and the imported reference) finish in seconds.  head_dim stays 64 as in every LlamaGen size."""
+    return PathConfig(
+        gpt=GPTConfig(dim=256, n_layer=6, n_head=4, vocab_size=vocab_size, block_size=block_size,
+                      condition_type=condition_type),
+        vit=ViTConfig(hidden=128, layers=3, heads=2),
+        vq=VQConfig(codebook_size=vocab_size, z_channels=64, ch=32),
+    )

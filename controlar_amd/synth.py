@@ -1,0 +1,207 @@
+"""Deterministic synthetic weights and inputs (no checkpoints or datasets exist offline).
+
+The recipe is SURVEY.md §8(d): reference-shaped state dicts keyed by the reference's own
+parameter names (gpt_t2i.Transformer, HF Dinov2Model under ``adapter.model.``, VQModel),
+drawn from a seeded torch CPU generator so the imported reference (golden script), the CPU
+oracle and the HIP path all consume bit-identical fp32 tensors.
+
+Why not the reference's own init: ``output.weight`` and every ``MLP`` are zero-initialised
+(gpt_t2i.py:377,174-175) so logits and control tokens would be identically 0.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from .config import PathConfig, GPTConfig, ViTConfig, VQConfig
+
+
+class _Rng:
+    def __init__(self, seed: int):
+        self.g = torch.Generator(device="cpu")
+        self.g.manual_seed(seed)
+
+    def normal(self, *shape, std=1.0, mean=0.0):
+        return torch.randn(*shape, generator=self.g, dtype=torch.float32) * std + mean
+
+    def uniform(self, *shape, lo=-1.0, hi=1.0):
+        return torch.rand(*shape, generator=self.g, dtype=torch.float32) * (hi - lo) + lo
+
+
+def gpt_state_dict(cfg: GPTConfig, vit: ViTConfig, seed: int = 0, ctrl_gain: float = 1.1) -> Dict[str, torch.Tensor]:
+    """Names follow gpt_t2i.Transformer.state_dict() (reference gpt_t2i.py:310-349).
+    SURVEY §8(d) recipe: embeddings N(0,1), transformer linears N(0,0.03^2), output.weight
+    N(0,0.2^2); the text/control MLPs are fan-in scaled so control tokens are O(0.3) at every size."""
+    r = _Rng(seed)
+    D, H = cfg.dim, cfg.ffn_hidden
+    lin = 0.03
+    ctrl = ctrl_gain * D ** -0.5
+    sd: Dict[str, torch.Tensor] = {}
+    sd["tok_embeddings.weight"] = r.normal(cfg.vocab_size, D, std=1.0)
+    sd["cls_embedding.cap_proj.fc1.weight"] = r.normal(D, cfg.caption_dim, std=3.0 * cfg.caption_dim ** -0.5)
+    sd["cls_embedding.cap_proj.fc2.weight"] = r.normal(D, D, std=3.0 * D ** -0.5)
+    sd["cls_embedding.uncond_embedding"] = r.normal(cfg.cls_token_num, cfg.caption_dim, std=cfg.caption_dim ** -0.5)
+    sd["adapter_mlp.fc1.weight"] = r.normal(D, vit.hidden, std=ctrl_gain * vit.hidden ** -0.5)
+    sd["adapter_mlp.fc2.weight"] = r.normal(D, D, std=ctrl)
+    sd["condition_mlp.cap_proj.fc1.weight"] = r.normal(D, D, std=ctrl)
+    sd["condition_mlp.cap_proj.fc2.weight"] = r.normal(D, D, std=ctrl)
+    for k in range(3):
+        sd[f"condition_layers.{k}.fc1.weight"] = r.normal(D, D, std=ctrl)
+        sd[f"condition_layers.{k}.fc2.weight"] = r.normal(D, D, std=ctrl)
+    for i in range(cfg.n_layer):
+        p = f"layers.{i}."
+        sd[p + "attention.wqkv.weight"] = r.normal(3 * D, D, std=lin)
+        sd[p + "attention.wo.weight"] = r.normal(D, D, std=lin)
+        sd[p + "feed_forward.w1.weight"] = r.normal(H, D, std=lin)
+        sd[p + "feed_forward.w3.weight"] = r.normal(H, D, std=lin)
+        sd[p + "feed_forward.w2.weight"] = r.normal(D, H, std=lin)
+        sd[p + "attention_norm.weight"] = r.normal(D, std=0.1, mean=1.0)
+        sd[p + "ffn_norm.weight"] = r.normal(D, std=0.1, mean=1.0)
+    sd["norm.weight"] = r.normal(D, std=0.1, mean=1.0)
+    sd["output.weight"] = r.normal(cfg.vocab_size, D, std=0.2)
+    return sd
+
+
+def vit_state_dict(cfg: ViTConfig, seed: int = 1, prefix: str = "adapter.model.") -> Dict[str, torch.Tensor]:
+    """Names follow HF Dinov2Model.state_dict() (transformers 5.15.0 modeling_dinov2.py)."""
+    r = _Rng(seed)
+    D, M = cfg.hidden, cfg.mlp
+    n_pos = cfg.pos_grid * cfg.pos_grid + 1
+    sd: Dict[str, torch.Tensor] = {}
+    e = prefix + "embeddings."
+    sd[e + "cls_token"] = r.normal(1, 1, D, std=0.02)
+    sd[e + "mask_token"] = torch.zeros(1, D)
+    sd[e + "position_embeddings"] = r.normal(1, n_pos, D, std=0.2)
+    fan_in = 3 * cfg.patch * cfg.patch
+    sd[e + "patch_embeddings.projection.weight"] = r.normal(D, 3, cfg.patch, cfg.patch, std=fan_in ** -0.5)
+    sd[e + "patch_embeddings.projection.bias"] = r.normal(D, std=0.02)
+    for i in range(cfg.layers):
+        p = f"{prefix}encoder.layer.{i}."
+        sd[p + "norm1.weight"] = r.normal(D, std=0.1, mean=1.0)
+        sd[p + "norm1.bias"] = r.normal(D, std=0.05)
+        for n in ("query", "key", "value"):
+            sd[p + f"attention.attention.{n}.weight"] = r.normal(D, D, std=D ** -0.5)
+            sd[p + f"attention.attention.{n}.bias"] = r.normal(D, std=0.02)
+        sd[p + "attention.output.dense.weight"] = r.normal(D, D, std=D ** -0.5)
+        sd[p + "attention.output.dense.bias"] = r.normal(D, std=0.02)
+        sd[p + "layer_scale1.lambda1"] = r.normal(D, std=0.05, mean=0.5)
+        sd[p + "norm2.weight"] = r.normal(D, std=0.1, mean=1.0)
+        sd[p + "norm2.bias"] = r.normal(D, std=0.05)
+        sd[p + "mlp.fc1.weight"] = r.normal(M, D, std=D ** -0.5)
+        sd[p + "mlp.fc1.bias"] = r.normal(M, std=0.02)
+        sd[p + "mlp.fc2.weight"] = r.normal(D, M, std=M ** -0.5)
+        sd[p + "mlp.fc2.bias"] = r.normal(D, std=0.02)
+        sd[p + "layer_scale2.lambda1"] = r.normal(D, std=0.05, mean=0.5)
+    sd[prefix + "layernorm.weight"] = r.normal(D, std=0.1, mean=1.0)
+    sd[prefix + "layernorm.bias"] = r.normal(D, std=0.05)
+    return sd
+
+
+def _conv(r: _Rng, sd, name, cout, cin, k):
+    bound = 1.0 / math.sqrt(cin * k * k)
+    # gain ~sqrt(3): keeps activations O(1) through 30 conv layers with swish
+    sd[name + ".weight"] = r.uniform(cout, cin, k, k, lo=-bound, hi=bound) * 1.7
+    sd[name + ".bias"] = r.uniform(cout, lo=-bound, hi=bound)
+
+
+def _gn(r: _Rng, sd, name, c):
+    sd[name + ".weight"] = r.normal(c, std=0.1, mean=1.0)
+    sd[name + ".bias"] = r.normal(c, std=0.1)
+
+
+def vq_decoder_layout(cfg: VQConfig):
+    """Yields the decode-side module list in execution order (reference vq_model.py:129-195).
+    Items: ("res", name, cin, cout) | ("attn", name, c) | ("up", name, c)."""
+    nres = len(cfg.ch_mult)
+    block_in = cfg.ch * cfg.ch_mult[nres - 1]
+    out = [("res", "decoder.mid.0", block_in, block_in), ("attn", "decoder.mid.1", block_in),
+           ("res", "decoder.mid.2", block_in, block_in)]
+    for idx, i_level in enumerate(reversed(range(nres))):
+        block_out = cfg.ch * cfg.ch_mult[i_level]
+        for j in range(cfg.num_res_blocks + 1):
+            out.append(("res", f"decoder.conv_blocks.{idx}.res.{j}", block_in, block_out))
+            block_in = block_out
+            if i_level == nres - 1:
+                out.append(("attn", f"decoder.conv_blocks.{idx}.attn.{j}", block_in))
+        if i_level != 0:
+            out.append(("up", f"decoder.conv_blocks.{idx}.upsample", block_in))
+    return out, block_in
+
+
+def vq_state_dict(cfg: VQConfig, seed: int = 2) -> Dict[str, torch.Tensor]:
+    """Decode-side names of VQModel.state_dict() (reference vq_model.py:28-39,129-169)."""
+    r = _Rng(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    cb = r.uniform(cfg.codebook_size, cfg.codebook_embed_dim, lo=-1.0, hi=1.0)
+    sd["quantize.embedding.weight"] = torch.nn.functional.normalize(cb, p=2, dim=-1) * r.uniform(cfg.codebook_size, 1, lo=0.5, hi=1.5)
+    _conv(r, sd, "post_quant_conv", cfg.z_channels, cfg.codebook_embed_dim, 1)
+    layout, last = vq_decoder_layout(cfg)
+    block_in = cfg.ch * cfg.ch_mult[-1]
+    _conv(r, sd, "decoder.conv_in", block_in, cfg.z_channels, 3)
+    for item in layout:
+        if item[0] == "res":
+            _, name, cin, cout = item
+            _gn(r, sd, name + ".norm1", cin)
+            _conv(r, sd, name + ".conv1", cout, cin, 3)
+            _gn(r, sd, name + ".norm2", cout)
+            _conv(r, sd, name + ".conv2", cout, cout, 3)
+            if cin != cout:
+                _conv(r, sd, name + ".nin_shortcut", cout, cin, 1)
+        elif item[0] == "attn":
+            _, name, c = item
+            _gn(r, sd, name + ".norm", c)
+            for n in ("q", "k", "v", "proj_out"):
+                _conv(r, sd, f"{name}.{n}", c, c, 1)
+        else:
+            _, name, c = item
+            _conv(r, sd, name + ".conv", c, c, 3)
+    _gn(r, sd, "decoder.norm_out", last)
+    _conv(r, sd, "decoder.conv_out", 3, last, 3)
+    return sd
+
+
+def path_state_dicts(cfg: PathConfig, seed: int = 0):
+    gpt = gpt_state_dict(cfg.gpt, cfg.vit, seed=seed)
+    gpt.update(vit_state_dict(cfg.vit, seed=seed + 1))
+    vq = vq_state_dict(cfg.vq, seed=seed + 2)
+    return gpt, vq
+
+
+# ----------------------------------------------------------------------------- inputs
+def canny_like_control(batch: int, H: int, W: int, seed: int = 1234, density: float = 0.08) -> torch.Tensor:
+    """Binary edge-like map in {-1,+1}, 3 identical channels, as sample_t2i.py:123-125,141
+    produces from cv2.Canny (uint8 {0,255} -> 2*(x/255-0.5))."""
+    out = []
+    for i in range(batch):
+        g = torch.Generator().manual_seed(seed + i)
+        m = (torch.rand(H, W, generator=g) > (1.0 - density)).float()
+        out.append((2.0 * (m - 0.5))[None].repeat(3, 1, 1))
+    return torch.stack(out)
+
+
+def smooth_control(batch: int, H: int, W: int, seed: int = 1234) -> torch.Tensor:
+    """Smooth map in [-1,1] (depth / soft-edge stand-in): low-pass filtered noise, 3 channels."""
+    out = []
+    for i in range(batch):
+        g = torch.Generator().manual_seed(seed + i)
+        lo = torch.rand(1, 1, max(H // 32, 2), max(W // 32, 2), generator=g)
+        m = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=True)[0, 0]
+        out.append((2.0 * m - 1.0)[None].repeat(3, 1, 1))
+    return torch.stack(out)
+
+
+def text_embeddings(batch: int, T: int = 120, caption_dim: int = 2048, seed: int = 1234):
+    """0.2*randn caption features, valid length L~U{8..40}, LEFT-padded exactly as
+    sample_t2i.py:146-160: valid tokens occupy the last L slots, features multiplied by mask."""
+    embs, masks = [], []
+    for i in range(batch):
+        g = torch.Generator().manual_seed(seed + i)
+        e = 0.2 * torch.randn(T, caption_dim, generator=g)
+        L = int(torch.randint(8, min(41, T + 1), (1,), generator=g).item())
+        m = torch.zeros(T, dtype=torch.int64)
+        m[T - L:] = 1
+        embs.append(e * m[:, None])
+        masks.append(m)
+    return torch.stack(embs), torch.stack(masks)
