@@ -1,0 +1,94 @@
+// car_common.h — shared device/host helpers for libcontrolar_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+
+__host__ __device__ inline float bf2f(bf16_t v) {
+    union { uint32_t u; float f; } c; c.u = ((uint32_t)v) << 16; return c.f;
+}
+// round-to-nearest-even, identical to torch's float->bfloat16
+__host__ __device__ inline bf16_t f2bf(float f) {
+    union { uint32_t u; float f; } c; c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// Element-type traits: T = float (exact mode) or bf16_t (fast mode)
+template <typename T> struct ET;
+template <> struct ET<float> {
+    static constexpr int mode = 0;
+    __host__ __device__ static inline float ld(const float* p) { return *p; }
+    __host__ __device__ static inline void st(float* p, float v) { *p = v; }
+    __host__ __device__ static inline float rnd(float v) { return v; }
+};
+template <> struct ET<bf16_t> {
+    static constexpr int mode = 1;
+    __host__ __device__ static inline float ld(const bf16_t* p) { return bf2f(*p); }
+    __host__ __device__ static inline void st(bf16_t* p, float v) { *p = f2bf(v); }
+    __host__ __device__ static inline float rnd(float v) { return bf2f(f2bf(v)); }
+};
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x multiple of 64 (<= 1024); `sm` has >= 17 floats
+__device__ inline float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sm[i];   // fixed order: deterministic
+    return r;
+}
+__device__ inline float block_max(float v, float* sm) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    float r = sm[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, sm[i]);
+    return r;
+}
+
+__device__ inline float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ inline float gelu_tanh_f(float x) {
+    const float k = 0.79788456080286535588f;   // sqrt(2/pi)
+    return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+__device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+enum { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_SILU = 3 };
+enum { BIAS_NONE = 0, BIAS_N = 1, BIAS_M = 2 };
+enum { AMODE_PLAIN = 0, AMODE_CONV3 = 1 };
+
+// Generic GEMM descriptor: C[z][m,n] = epi( alpha * sum_k A[z][m,k] * W[z][n,k] )   (both K-contiguous)
+struct GemmP {
+    const void* A; const void* W; void* C;
+    const void* bias; const void* scale; const void* R;   // bias: T per n or per m; scale: T per n; R: residual T [m,n]
+    int M, N, K;
+    long lda, ldw, ldc, ldr;
+    long sA0, sA1, sW0, sW1, sC0, sC1, sR0, sR1;          // batch strides: z = z0*nb1 + z1
+    int nb0, nb1;
+    float alpha;
+    int bias_mode, act, out_f32, swiglu;
+    // AMODE_CONV3: A is NHWC [B,Hin,Win,Cin]; output grid Ho x Wo (= Hin<<ups); K = 9*Cin; M = B*Ho*Wo
+    int Ho, Wo, Cin, ups;
+};

@@ -1,0 +1,863 @@
+// engine.hip — context, weight packing and orchestration behind the C ABI of include/controlar_hip.h.
+//
+// Stages:  A resize+patchify -> B DINOv2 -> C control MLPs -> D text embed ->
+// E prefill -> F decode loop (hipGraph-captured step replayed n_new-1 times, position/token fed
+// back on device) -> G CFG+sampling -> H VQ decode.  Everything below is enqueued on the context's
+// own stream (graph capture is illegal on the legacy default stream torch uses by default) and
+// fenced against the caller's stream with events — no host synchronisation inside the token loop.
+#include "car_common.h"
+#include "../../include/controlar_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ---- launchers implemented in gemm.hip / ops.hip / decode.hip
+struct NormP {
+    const void* h_in; const void* emb; const int* idx; void* h_out; void* xn; const void* w;
+    const void* ctrl; const int* pos; int add_mode; int T; int n_tok; float cs;
+    int D; float eps;
+};
+struct SampleP {
+    const float* logits; int B, V, use_cfg; float cfg_scale; int cfg_interval;
+    const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
+};
+struct AttnP {
+    const void* qkv; void* kcache; void* vcache; const float* rope; const int* pos; const unsigned char* emb_mask;
+    void* out; float* part; int H, S_max, T, dim, nsplit;
+};
+extern "C" {
+void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
+void car_launch_convert(int mode, const void* src, int src_dtype, void* dst, long n, hipStream_t st);
+void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg, hipStream_t st);
+void car_launch_layernorm(int mode, const void* x, const void* w, const void* b, void* y, long rows, int D, float eps, hipStream_t st);
+void car_launch_rmsnorm(int mode, const NormP* p, long rows, hipStream_t st);
+void car_launch_softmax(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, int mask_mode,
+                        const unsigned char* emb_mask, int Tq, int n_head, hipStream_t st);
+void car_launch_patchify(int mode, const void* img, int img_dtype, void* out, int B, int H, int W, int gh, int gw, int p, int Kpad,
+                         int bicubic, const int* iy, const int* ix, const float* wy, const float* wx, hipStream_t st);
+void car_launch_vit_assemble(int mode, const void* tok, const void* cls, const void* pos, void* h, int B, int n, int D, hipStream_t st);
+void car_launch_groupnorm(int mode, const void* x, const void* gamma, const void* beta, void* y, float* part, float* stats,
+                          int B, int HW, int C, int G, float eps, int swish, hipStream_t st);
+void car_launch_vq_lookup(int mode, const int* tok, const float* cb, const float* wpq, const float* bpq, void* z, long npix, int cd, int zc, int ncode, hipStream_t st);
+void car_launch_conv_out(int mode, const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int C, hipStream_t st);
+void car_launch_swiglu(int mode, const void* in, void* out, long rows, int hidden, hipStream_t st);
+void car_launch_sample_greedy(const SampleP* p, hipStream_t st);
+void car_launch_advance(int* pos, int* step, hipStream_t st);
+void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st);
+void car_launch_dec_attn(int mode, const AttnP* p, int b, hipStream_t st);
+void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, hipStream_t st);
+}
+
+static thread_local std::string g_create_err;
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + (bytes >> 3) + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+        cap = want; return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Wt { void* p = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
+
+struct car_ctx {
+    car_config cfg; int mode = 0; size_t esz = 4;
+    std::string err;
+    hipStream_t stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
+    std::unordered_map<std::string, Wt> w;            // packed weights by (reference) name, element type T unless noted
+    std::unordered_map<std::string, std::vector<float>> host_keep;   // host fp32 copies needed later (pos-emb, w1/w3 halves)
+    bool finalized = false;
+    // cached tables
+    std::map<std::pair<int, int>, void*> pos_cache;   // (gh,gw) -> T [1+gh*gw, D]
+    struct ResizeTab { int* iy; int* ix; float* wy; float* wx; };
+    std::map<std::pair<int, int>, ResizeTab> resize_cache;
+    float* rope = nullptr; int rope_rows = 0;
+    // buffers
+    DevBuf ctrl_in;      // [B, n_tok, dim] T — adapter_mlp output of the last car_encode_control
+    int ctrl_B = 0, ctrl_ntok = 0;
+    DevBuf ctrl[3];      // cached control tokens [b, n_tok, dim]
+    DevBuf kv;           // [n_layer][2][b, H, S_max, 64]
+    DevBuf ws[12];       // scratch
+    DevBuf scal;         // device ints: pos, step, cur_tok[b]
+    DevBuf tok_out;      // [B, n_new] int32
+    DevBuf maskb;        // [b, T] uint8
+    // decode graph
+    hipGraphExec_t gexec = nullptr; std::string gkey;
+    car_stats stats;
+    int n_dec_kernels = 0;
+};
+
+#define FAIL(ctx, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return -1; } while (0)
+#define HIPCHK(ctx, x) do { hipError_t _e = (x); if (_e != hipSuccess) FAIL(ctx, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+#define NEED(ctx, buf, bytes) do { if (!(buf).ensure(bytes)) FAIL(ctx, "out of device memory allocating %zu bytes (%s:%d)", (size_t)(bytes), __FILE__, __LINE__); } while (0)
+
+static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------- lifecycle
+extern "C" int car_abi_version(void) { return CAR_ABI_VERSION; }
+
+extern "C" const char* car_last_error(const car_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int car_create(car_ctx** out, const car_config* cfg) {
+    if (!out || !cfg) { g_create_err = "car_create: null argument"; return -1; }
+    *out = nullptr;
+    if (cfg->abi_version != CAR_ABI_VERSION) { g_create_err = "car_create: abi_version mismatch"; return -1; }
+    if (cfg->mode != CAR_F32 && cfg->mode != CAR_BF16) { g_create_err = "car_create: mode must be CAR_F32 or CAR_BF16"; return -1; }
+    if (cfg->dim <= 0 || cfg->n_layer < 3 || cfg->n_head <= 0 || cfg->ffn_hidden <= 0 || cfg->vocab_size <= 0 || cfg->cls_token_num <= 0 ||
+        cfg->block_size <= 0 || cfg->caption_dim <= 0 || cfg->vit_hidden <= 0 || cfg->vit_layers <= 0 || cfg->vit_heads <= 0 || cfg->vit_mlp <= 0 ||
+        cfg->vit_patch <= 0 || cfg->vit_pos_grid <= 0 || cfg->vq_n_mult < 1 || cfg->vq_n_mult > 8) {
+        g_create_err = "car_create: non-positive dimension in car_config"; return -1; }
+    if (cfg->dim % cfg->n_head != 0 || cfg->dim / cfg->n_head != 64) { g_create_err = "car_create: head_dim must be 64 (every LlamaGen size)"; return -1; }
+    if (cfg->dim % 32 || cfg->ffn_hidden % 32 || cfg->caption_dim % 32 || cfg->vit_hidden % 32 || cfg->vit_mlp % 32) {
+        g_create_err = "car_create: dim, ffn_hidden, caption_dim, vit_hidden, vit_mlp must be multiples of 32"; return -1; }
+    if (cfg->vit_hidden % cfg->vit_heads != 0 || (cfg->vit_hidden / cfg->vit_heads) % 32) { g_create_err = "car_create: ViT head_dim must be a multiple of 32"; return -1; }
+    int g = (int)std::lround(std::sqrt((double)cfg->block_size));
+    if (g * g != cfg->block_size) { g_create_err = "car_create: block_size must be a square (gpt_t2i.py:352)"; return -1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "car_create: no HIP device visible (this library has no CPU fallback)"; return -1; }
+    car_ctx* c = new car_ctx();
+    c->cfg = *cfg; c->mode = cfg->mode; c->esz = cfg->mode == CAR_BF16 ? 2 : 4;
+    memset(&c->stats, 0, sizeof(c->stats));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess || hipEventCreate(&c->ev_t2) != hipSuccess) {
+        g_create_err = "car_create: stream/event creation failed"; delete c; return -1;
+    }
+    // 2-D RoPE table (gpt_t2i.py:506-519): rows [0,T) zero, then grid*grid rows of (cos,sin) x 32 pairs
+    {
+        const int T = cfg->cls_token_num, half = 32, quarter = 16;
+        c->rope_rows = T + g * g;
+        std::vector<float> tab((size_t)c->rope_rows * 32 * 2, 0.f);
+        std::vector<float> freqs(quarter);
+        for (int i = 0; i < quarter; ++i) freqs[i] = 1.0f / std::pow((float)cfg->rope_base, (float)(2 * i) / (float)half);
+        for (int y = 0; y < g; ++y) for (int x = 0; x < g; ++x) {
+            float* row = &tab[((size_t)T + (size_t)y * g + x) * 64];
+            for (int i = 0; i < quarter; ++i) {
+                const float fy = (float)y * freqs[i], fx = (float)x * freqs[i];
+                row[2 * i] = (float)std::cos((double)fy); row[2 * i + 1] = (float)std::sin((double)fy);
+                row[2 * (quarter + i)] = (float)std::cos((double)fx); row[2 * (quarter + i) + 1] = (float)std::sin((double)fx);
+            }
+        }
+        if (hipMalloc((void**)&c->rope, tab.size() * 4) != hipSuccess ||
+            hipMemcpy(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            g_create_err = "car_create: rope table upload failed"; delete c; return -1;
+        }
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void car_destroy(car_ctx* c) {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+    for (auto& kv : c->w) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : c->pos_cache) (void)hipFree(kv.second);
+    for (auto& kv : c->resize_cache) { (void)hipFree(kv.second.iy); (void)hipFree(kv.second.ix); if (kv.second.wy) (void)hipFree(kv.second.wy); if (kv.second.wx) (void)hipFree(kv.second.wx); }
+    if (c->rope) (void)hipFree(c->rope);
+    c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
+    c->scal.release(); c->tok_out.release(); c->maskb.release();
+    (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------- weights
+static bool ends_with(const std::string& s, const char* suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
+static bool starts_with(const std::string& s, const char* pre) { return s.compare(0, strlen(pre), pre) == 0; }
+
+// upload a host fp32 array as element type T (or as fp32 when force_f32)
+static int upload(car_ctx* c, const std::string& name, const std::vector<float>& h, const std::vector<int64_t>& shape, bool force_f32 = false) {
+    Wt t; t.shape = shape; t.numel = (int64_t)h.size();
+    const bool f32 = force_f32 || c->mode == CAR_F32;
+    const size_t bytes = h.size() * (f32 ? 4 : 2);
+    HIPCHK(c, hipMalloc(&t.p, bytes ? bytes : 4));
+    if (f32) { HIPCHK(c, hipMemcpy(t.p, h.data(), bytes, hipMemcpyHostToDevice)); }
+    else {
+        std::vector<bf16_t> hb(h.size());
+        for (size_t i = 0; i < h.size(); ++i) hb[i] = f2bf(h[i]);
+        HIPCHK(c, hipMemcpy(t.p, hb.data(), bytes, hipMemcpyHostToDevice));
+    }
+    auto it = c->w.find(name);
+    if (it != c->w.end() && it->second.p) (void)hipFree(it->second.p);
+    c->w[name] = t;
+    return 0;
+}
+
+extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, const int64_t* shape, int32_t ndim, int32_t dtype) {
+    if (!c || !cname || !ptr || (ndim > 0 && !shape)) { if (c) c->err = "car_load_tensor: null argument"; return -1; }
+    if (dtype != CAR_DT_F32 && dtype != CAR_DT_BF16) FAIL(c, "car_load_tensor(%s): dtype must be F32 or BF16", cname);
+    const std::string name(cname);
+    // reference tensors that the inference path never reads
+    if (name == "condition_embeddings.weight" || name == "condition_mlp.uncond_embedding" || ends_with(name, "mask_token") ||
+        starts_with(name, "encoder.") || starts_with(name, "quant_conv.") || name == "quantize.codebook_used") return 0;
+    std::vector<int64_t> shp(shape, shape + ndim);
+    int64_t n = 1; for (auto s : shp) n *= s;
+    // bring to host fp32
+    std::vector<float> h((size_t)n);
+    {
+        hipPointerAttribute_t at; bool on_dev = false;
+        if (hipPointerGetAttributes(&at, ptr) == hipSuccess) on_dev = (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged);
+        else (void)hipGetLastError();
+        const size_t eb = dtype == CAR_DT_F32 ? 4 : 2;
+        std::vector<unsigned char> raw;
+        const void* src = ptr;
+        if (on_dev) { raw.resize((size_t)n * eb); HIPCHK(c, hipMemcpy(raw.data(), ptr, raw.size(), hipMemcpyDeviceToHost)); src = raw.data(); }
+        if (dtype == CAR_DT_F32) memcpy(h.data(), src, (size_t)n * 4);
+        else { const bf16_t* b = (const bf16_t*)src; for (int64_t i = 0; i < n; ++i) h[(size_t)i] = bf2f(b[i]); }
+    }
+    const car_config& g = c->cfg;
+    c->finalized = false;
+    // ---- name-specific packing
+    if (ends_with(name, "feed_forward.w1.weight") || ends_with(name, "feed_forward.w3.weight")) {
+        // w1 | w3 interleaved in blocks of 16 rows so the GEMM epilogue sees (a, c) pairs (gemm.hip SWIGLU)
+        if (ndim != 2 || shp[0] != g.ffn_hidden || shp[1] != g.dim) FAIL(c, "%s: expected [%d,%d]", cname, g.ffn_hidden, g.dim);
+        const bool is1 = ends_with(name, "w1.weight");
+        const std::string base = name.substr(0, name.size() - strlen("w1.weight"));
+        const std::string other = base + (is1 ? "w3.weight" : "w1.weight");
+        auto it = c->host_keep.find(other);
+        if (it == c->host_keep.end()) { c->host_keep[name] = std::move(h); return 0; }
+        const std::vector<float>& w1 = is1 ? h : it->second; const std::vector<float>& w3 = is1 ? it->second : h;
+        std::vector<float> pk((size_t)2 * g.ffn_hidden * g.dim);
+        for (int r = 0; r < g.ffn_hidden; ++r) {
+            const size_t blk = (size_t)(r / 16) * 32 + (r % 16);
+            memcpy(&pk[blk * g.dim], &w1[(size_t)r * g.dim], (size_t)g.dim * 4);
+            memcpy(&pk[(blk + 16) * g.dim], &w3[(size_t)r * g.dim], (size_t)g.dim * 4);
+        }
+        int rc = upload(c, base + "w13.weight", pk, {2 * (int64_t)g.ffn_hidden, g.dim});
+        c->host_keep.erase(other);
+        return rc;
+    }
+    if (name == "adapter.model.embeddings.position_embeddings") { c->host_keep[name] = h; return 0; }   // interpolated per resolution
+    if (name == "adapter.model.embeddings.patch_embeddings.projection.weight") {
+        // [D,3,p,p] -> [D, Kpad] zero padded to a multiple of 32
+        const int K = 3 * g.vit_patch * g.vit_patch, Kp = (int)rup(K, 32);
+        if (n != (int64_t)g.vit_hidden * K) FAIL(c, "%s: bad shape", cname);
+        std::vector<float> pk((size_t)g.vit_hidden * Kp, 0.f);
+        for (int d = 0; d < g.vit_hidden; ++d) memcpy(&pk[(size_t)d * Kp], &h[(size_t)d * K], (size_t)K * 4);
+        return upload(c, name, pk, {g.vit_hidden, Kp});
+    }
+    if (name == "quantize.embedding.weight" || starts_with(name, "post_quant_conv.")) return upload(c, name, h, shp, true);
+    if (name == "decoder.conv_out.weight") {
+        // [3,C,3,3] -> [3][9][C]
+        const int C = (int)shp[1];
+        std::vector<float> pk(h.size());
+        for (int o = 0; o < 3; ++o) for (int ci = 0; ci < C; ++ci) for (int t = 0; t < 9; ++t)
+            pk[((size_t)o * 9 + t) * C + ci] = h[((size_t)o * C + ci) * 9 + t];
+        return upload(c, name, pk, {3, 9, C});
+    }
+    if (name == "decoder.conv_out.bias") return upload(c, name, h, shp, true);
+    if (starts_with(name, "decoder.") && ndim == 4 && shp[2] == 3) {
+        // conv3x3 [Co,Ci,3,3] -> implicit-GEMM weight [Co, 9*Ci], k = tap*Ci + ci
+        const int Co = (int)shp[0], Ci = (int)shp[1];
+        std::vector<float> pk(h.size());
+        for (int o = 0; o < Co; ++o) for (int ci = 0; ci < Ci; ++ci) for (int t = 0; t < 9; ++t)
+            pk[((size_t)o * 9 + t) * Ci + ci] = h[((size_t)o * Ci + ci) * 9 + t];
+        return upload(c, name, pk, {Co, 9 * (int64_t)Ci});
+    }
+    if (starts_with(name, "decoder.") && ndim == 4) return upload(c, name, h, {shp[0], shp[1]});   // 1x1 conv
+    return upload(c, name, h, shp);
+}
+
+static const void* Wp(car_ctx* c, const std::string& name) {
+    auto it = c->w.find(name);
+    return it == c->w.end() ? nullptr : it->second.p;
+}
+
+struct VqItem { int kind; std::string name; int cin, cout; };   // 0 res, 1 attn, 2 up
+static std::vector<VqItem> vq_layout(const car_config& g, int* last_c) {
+    // reference: vq_model.py:129-169 (Decoder.__init__), :174-195 (forward order)
+    std::vector<VqItem> v;
+    const int nres = g.vq_n_mult;
+    int block_in = g.vq_ch * g.vq_ch_mult[nres - 1];
+    v.push_back({0, "decoder.mid.0", block_in, block_in}); v.push_back({1, "decoder.mid.1", block_in, block_in}); v.push_back({0, "decoder.mid.2", block_in, block_in});
+    for (int idx = 0; idx < nres; ++idx) {
+        const int i_level = nres - 1 - idx, block_out = g.vq_ch * g.vq_ch_mult[i_level];
+        for (int j = 0; j < g.vq_num_res_blocks + 1; ++j) {
+            v.push_back({0, "decoder.conv_blocks." + std::to_string(idx) + ".res." + std::to_string(j), block_in, block_out});
+            block_in = block_out;
+            if (i_level == nres - 1) v.push_back({1, "decoder.conv_blocks." + std::to_string(idx) + ".attn." + std::to_string(j), block_in, block_in});
+        }
+        if (i_level != 0) v.push_back({2, "decoder.conv_blocks." + std::to_string(idx) + ".upsample", block_in, block_in});
+    }
+    *last_c = block_in;
+    return v;
+}
+
+extern "C" int car_finalize_weights(car_ctx* c) {
+    if (!c) return -1;
+    const car_config& g = c->cfg;
+    std::vector<std::string> req = {
+        "tok_embeddings.weight", "cls_embedding.cap_proj.fc1.weight", "cls_embedding.cap_proj.fc2.weight", "cls_embedding.uncond_embedding",
+        "adapter_mlp.fc1.weight", "adapter_mlp.fc2.weight", "condition_mlp.cap_proj.fc1.weight", "condition_mlp.cap_proj.fc2.weight",
+        "norm.weight", "output.weight" };
+    for (int k = 0; k < 3; ++k) { req.push_back("condition_layers." + std::to_string(k) + ".fc1.weight"); req.push_back("condition_layers." + std::to_string(k) + ".fc2.weight"); }
+    for (int i = 0; i < g.n_layer; ++i) {
+        const std::string p = "layers." + std::to_string(i) + ".";
+        for (const char* s : {"attention.wqkv.weight", "attention.wo.weight", "feed_forward.w13.weight", "feed_forward.w2.weight", "attention_norm.weight", "ffn_norm.weight"}) req.push_back(p + s);
+    }
+    const std::string a = "adapter.model.";
+    for (const char* s : {"embeddings.cls_token", "embeddings.patch_embeddings.projection.weight", "embeddings.patch_embeddings.projection.bias", "layernorm.weight", "layernorm.bias"}) req.push_back(a + s);
+    for (int i = 0; i < g.vit_layers; ++i) {
+        const std::string p = a + "encoder.layer." + std::to_string(i) + ".";
+        for (const char* s : {"norm1.weight", "norm1.bias", "attention.attention.query.weight", "attention.attention.query.bias", "attention.attention.key.weight",
+                              "attention.attention.key.bias", "attention.attention.value.weight", "attention.attention.value.bias", "attention.output.dense.weight",
+                              "attention.output.dense.bias", "layer_scale1.lambda1", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
+                              "mlp.fc2.bias", "layer_scale2.lambda1"}) req.push_back(p + s);
+    }
+    std::string missing;
+    int nmiss = 0;
+    for (auto& r : req) if (!Wp(c, r)) { if (nmiss < 6) missing += r + " "; ++nmiss; }
+    if (c->host_keep.find("adapter.model.embeddings.position_embeddings") == c->host_keep.end()) { missing += "adapter.model.embeddings.position_embeddings "; ++nmiss; }
+    // the VQ decoder is optional as a group (a context may serve generate() only) but must be complete if present
+    if (Wp(c, "quantize.embedding.weight")) {
+        int last = 0;
+        std::vector<std::string> vr = {"post_quant_conv.weight", "post_quant_conv.bias", "decoder.conv_in.weight", "decoder.conv_in.bias",
+                                       "decoder.norm_out.weight", "decoder.norm_out.bias", "decoder.conv_out.weight", "decoder.conv_out.bias"};
+        for (auto& it : vq_layout(g, &last)) {
+            if (it.kind == 0) { for (const char* s : {".norm1.weight", ".norm1.bias", ".conv1.weight", ".conv1.bias", ".norm2.weight", ".norm2.bias", ".conv2.weight", ".conv2.bias"}) vr.push_back(it.name + s);
+                                if (it.cin != it.cout) { vr.push_back(it.name + ".nin_shortcut.weight"); vr.push_back(it.name + ".nin_shortcut.bias"); } }
+            else if (it.kind == 1) { for (const char* s : {".norm.weight", ".norm.bias", ".q.weight", ".q.bias", ".k.weight", ".k.bias", ".v.weight", ".v.bias", ".proj_out.weight", ".proj_out.bias"}) vr.push_back(it.name + s); }
+            else { vr.push_back(it.name + ".conv.weight"); vr.push_back(it.name + ".conv.bias"); }
+        }
+        for (auto& r : vr) if (!Wp(c, r)) { if (nmiss < 6) missing += r + " "; ++nmiss; }
+    }
+    if (nmiss) FAIL(c, "car_finalize_weights: %d required tensors missing, e.g. %s", nmiss, missing.c_str());
+    c->finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- small host-side tables
+static void cubic_coeffs(float t, float w[4]) {   // ATen get_cubic_upsample_coefficients, A = -0.75
+    const float A = -0.75f;
+    float x0 = t + 1.0f; w[0] = ((A * x0 - 5 * A) * x0 + 8 * A) * x0 - 4 * A;
+    w[1] = ((A + 2) * t - (A + 3)) * t * t + 1;
+    float x2 = 1.0f - t; w[2] = ((A + 2) * x2 - (A + 3)) * x2 * x2 + 1;
+    float x3 = 2.0f - t; w[3] = ((A * x3 - 5 * A) * x3 + 8 * A) * x3 - 4 * A;
+}
+static void bicubic_tab(int out, int in, bool align, std::vector<int>& idx, std::vector<float>& wt) {
+    idx.resize((size_t)out * 4); wt.resize((size_t)out * 4);
+    for (int d = 0; d < out; ++d) {
+        float src;
+        if (align) { float sc = out > 1 ? (float)((double)(in - 1) / (double)(out - 1)) : 0.f; src = (float)d * sc; }
+        else { float sc = (float)((double)in / (double)out); src = ((float)d + 0.5f) * sc - 0.5f; }
+        float fl = std::floor(src); float t = src - fl; int ix = (int)fl;
+        cubic_coeffs(t, &wt[(size_t)d * 4]);
+        for (int k = 0; k < 4; ++k) { int v = ix - 1 + k; v = v < 0 ? 0 : (v > in - 1 ? in - 1 : v); idx[(size_t)d * 4 + k] = v; }
+    }
+}
+
+static int get_resize(car_ctx* c, int H, int W, int nh, int nw, car_ctx::ResizeTab* out) {
+    auto key = std::make_pair(H, W);
+    auto it = c->resize_cache.find(key);
+    if (it != c->resize_cache.end()) { *out = it->second; return 0; }
+    car_ctx::ResizeTab t{nullptr, nullptr, nullptr, nullptr};
+    if (c->cfg.resize_mode == CAR_RESIZE_NEAREST) {
+        // ATen nearest: floor(dst * (float)in/out) in fp32, clamped (dinov2_adapter.py:20)
+        std::vector<int> iy(nh), ix(nw);
+        const float sy = (float)((double)H / (double)nh), sx = (float)((double)W / (double)nw);
+        for (int i = 0; i < nh; ++i) { int v = (int)std::floor((float)i * sy); iy[i] = v > H - 1 ? H - 1 : v; }
+        for (int i = 0; i < nw; ++i) { int v = (int)std::floor((float)i * sx); ix[i] = v > W - 1 ? W - 1 : v; }
+        HIPCHK(c, hipMalloc((void**)&t.iy, nh * 4)); HIPCHK(c, hipMalloc((void**)&t.ix, nw * 4));
+        HIPCHK(c, hipMemcpy(t.iy, iy.data(), nh * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(t.ix, ix.data(), nw * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<int> iy, ix; std::vector<float> wy, wx;
+        bicubic_tab(nh, H, true, iy, wy); bicubic_tab(nw, W, true, ix, wx);
+        HIPCHK(c, hipMalloc((void**)&t.iy, iy.size() * 4)); HIPCHK(c, hipMalloc((void**)&t.ix, ix.size() * 4));
+        HIPCHK(c, hipMalloc((void**)&t.wy, wy.size() * 4)); HIPCHK(c, hipMalloc((void**)&t.wx, wx.size() * 4));
+        HIPCHK(c, hipMemcpy(t.iy, iy.data(), iy.size() * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(t.ix, ix.data(), ix.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(t.wy, wy.data(), wy.size() * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(t.wx, wx.data(), wx.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->resize_cache[key] = t; *out = t;
+    return 0;
+}
+
+// HF Dinov2Embeddings.interpolate_pos_encoding (:57-95): bicubic align_corners=False in fp32, per (gh,gw), cached
+static int get_pos_embed(car_ctx* c, int gh, int gw, void** out) {
+    auto key = std::make_pair(gh, gw);
+    auto it = c->pos_cache.find(key);
+    if (it != c->pos_cache.end()) { *out = it->second; return 0; }
+    const std::vector<float>& pe = c->host_keep["adapter.model.embeddings.position_embeddings"];
+    const int D = c->cfg.vit_hidden, G = c->cfg.vit_pos_grid;
+    if ((int64_t)pe.size() != (int64_t)(G * G + 1) * D) FAIL(c, "position_embeddings has %zu elements, expected %d", pe.size(), (G * G + 1) * D);
+    std::vector<float> o((size_t)(gh * gw + 1) * D);
+    memcpy(o.data(), pe.data(), (size_t)D * 4);
+    if (gh == G && gw == G) memcpy(o.data() + D, pe.data() + D, (size_t)G * G * D * 4);
+    else {
+        std::vector<int> iy, ix; std::vector<float> wy, wx;
+        bicubic_tab(gh, G, false, iy, wy); bicubic_tab(gw, G, false, ix, wx);
+        std::vector<float> rows((size_t)G * gw);
+        for (int d = 0; d < D; ++d) {
+            for (int y = 0; y < G; ++y) for (int x = 0; x < gw; ++x) {
+                float acc = 0.f;
+                for (int k = 0; k < 4; ++k) acc += pe[(size_t)(1 + y * G + ix[x * 4 + k]) * D + d] * wx[x * 4 + k];
+                rows[(size_t)y * gw + x] = acc;
+            }
+            for (int y = 0; y < gh; ++y) for (int x = 0; x < gw; ++x) {
+                float acc = 0.f;
+                for (int k = 0; k < 4; ++k) acc += rows[(size_t)iy[y * 4 + k] * gw + x] * wy[y * 4 + k];
+                o[(size_t)(1 + y * gw + x) * D + d] = acc;
+            }
+        }
+    }
+    void* dp = nullptr;
+    const size_t bytes = o.size() * c->esz;
+    HIPCHK(c, hipMalloc(&dp, bytes));
+    if (c->mode == CAR_F32) { HIPCHK(c, hipMemcpy(dp, o.data(), bytes, hipMemcpyHostToDevice)); }
+    else { std::vector<bf16_t> hb(o.size()); for (size_t i = 0; i < o.size(); ++i) hb[i] = f2bf(o[i]); HIPCHK(c, hipMemcpy(dp, hb.data(), bytes, hipMemcpyHostToDevice)); }
+    c->pos_cache[key] = dp; *out = dp;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- GEMM helpers
+static GemmP gp(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K) {
+    GemmP p; memset(&p, 0, sizeof(p));
+    p.A = A; p.W = W; p.C = C; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    p.alpha = 1.f; p.nb0 = 1; p.nb1 = 1;
+    return p;
+}
+static inline char* off(void* p, size_t elems, size_t esz) { return (char*)p + elems * esz; }
+static inline const char* off(const void* p, size_t elems, size_t esz) { return (const char*)p + elems * esz; }
+
+// y = fc2(gelu_tanh(fc1 x))   (gpt_t2i.py:165-181), x: [z][M, K] with row stride lda / batch stride sA
+static void mlp_tanh(car_ctx* c, const void* x, long lda, long sA, int nb, int M, int K, const std::string& pfx, void* mid, void* y, int dim, hipStream_t st) {
+    GemmP p = gp(x, lda, Wp(c, pfx + "fc1.weight"), K, mid, dim, M, dim, K);
+    p.act = ACT_GELU_TANH; p.nb0 = nb; p.sA0 = sA; p.sC0 = (long)M * dim;
+    car_launch_gemm(c->mode, AMODE_PLAIN, &p, st);
+    GemmP q = gp(mid, dim, Wp(c, pfx + "fc2.weight"), dim, y, dim, M * nb, dim, dim);
+    car_launch_gemm(c->mode, AMODE_PLAIN, &q, st);
+}
+
+static void fence_in(car_ctx* c, hipStream_t caller) { (void)hipEventRecord(c->ev_in, caller); (void)hipStreamWaitEvent(c->stream, c->ev_in, 0); }
+static void fence_out(car_ctx* c, hipStream_t caller) { (void)hipEventRecord(c->ev_out, c->stream); (void)hipStreamWaitEvent(caller, c->ev_out, 0); }
+
+// ------------------------------------------------------------------------------------- control encoder
+extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype, int32_t B, int32_t H, int32_t W, void* out, void* stream_) {
+    if (!c) return -1;
+    if (!c->finalized) FAIL(c, "car_encode_control: call car_finalize_weights first");
+    if (!img || B <= 0 || H < 16 || W < 16) FAIL(c, "car_encode_control: bad arguments");
+    if (img_dtype != CAR_DT_F32 && img_dtype != CAR_DT_BF16) FAIL(c, "car_encode_control: image dtype must be F32 or BF16");
+    const car_config& g = c->cfg;
+    hipStream_t caller = (hipStream_t)stream_, st = c->stream;
+    const int mode = c->mode; const size_t e = c->esz;
+    const int p = g.vit_patch, gh = H / 16, gw = W / 16, n = gh * gw, Tn = n + 1, D = g.vit_hidden, nh = g.vit_heads, hd = D / nh;
+    const int Kp = (int)rup(3 * p * p, 32), Tpad = (int)rup(Tn, 32);
+    car_ctx::ResizeTab rt; if (get_resize(c, H, W, gh * p, gw * p, &rt)) return -1;
+    void* pos = nullptr; if (get_pos_embed(c, gh, gw, &pos)) return -1;
+    NEED(c, c->ctrl_in, (size_t)B * n * g.dim * e);
+    c->ctrl_B = B; c->ctrl_ntok = n;
+    const int CH = B < 16 ? B : 16;    // images per chunk: bounds the fp32 score matrix (CH*heads*Tn*Tn*4 B)
+    NEED(c, c->ws[0], (size_t)CH * n * Kp * e);            // patches, later ctx
+    NEED(c, c->ws[1], (size_t)CH * Tn * D * e);            // h
+    NEED(c, c->ws[2], (size_t)CH * Tn * D * e);            // y (normed) / tok
+    NEED(c, c->ws[3], (size_t)CH * Tn * 3 * D * e);        // q | k | v (separate planes)
+    NEED(c, c->ws[4], (size_t)CH * nh * Tn * Tn * 4);      // S fp32
+    NEED(c, c->ws[5], (size_t)CH * nh * Tn * Tpad * e);    // P
+    NEED(c, c->ws[6], (size_t)CH * D * Tpad * e);          // V^T
+    NEED(c, c->ws[7], (size_t)CH * Tn * (g.vit_mlp > g.dim ? g.vit_mlp : g.dim) * e);   // mlp mid / adapter mid
+    NEED(c, c->ws[8], (size_t)CH * Tn * D * e);            // ctx
+    fence_in(c, caller);
+    const std::string a = "adapter.model.";
+    for (int b0 = 0; b0 < B; b0 += CH) {
+        const int nb = (B - b0) < CH ? (B - b0) : CH;
+        const size_t ibytes = img_dtype == CAR_DT_BF16 ? 2 : 4;
+        const void* im = (const char*)img + (size_t)b0 * 3 * H * W * ibytes;
+        void *patches = c->ws[0].p, *h = c->ws[1].p, *y = c->ws[2].p, *qkv = c->ws[3].p, *P = c->ws[5].p, *vT = c->ws[6].p, *mid = c->ws[7].p, *ctx = c->ws[8].p;
+        float* S = (float*)c->ws[4].p;
+        car_launch_patchify(mode, im, img_dtype, patches, nb, H, W, gh, gw, p, Kp, g.resize_mode == CAR_RESIZE_BICUBIC_AC, rt.iy, rt.ix, rt.wy, rt.wx, st);
+        {   // patch projection (HF :119-149) -> y used as tok buffer
+            GemmP q = gp(patches, Kp, Wp(c, a + "embeddings.patch_embeddings.projection.weight"), Kp, y, D, nb * n, D, Kp);
+            q.bias = Wp(c, a + "embeddings.patch_embeddings.projection.bias"); q.bias_mode = BIAS_N;
+            car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+        }
+        car_launch_vit_assemble(mode, y, Wp(c, a + "embeddings.cls_token"), pos, h, nb, n, D, st);
+        const long rows = (long)nb * Tn;
+        void* qp = qkv; void* kp = off(qkv, (size_t)rows * D, e); void* vp = off(qkv, (size_t)2 * rows * D, e);
+        for (int l = 0; l < g.vit_layers; ++l) {
+            const std::string L = a + "encoder.layer." + std::to_string(l) + ".";
+            car_launch_layernorm(mode, h, Wp(c, L + "norm1.weight"), Wp(c, L + "norm1.bias"), y, rows, D, g.vit_ln_eps, st);
+            const char* names[3] = {"query", "key", "value"}; void* dst[3] = {qp, kp, vp};
+            for (int t = 0; t < 3; ++t) {
+                GemmP q = gp(y, D, Wp(c, L + "attention.attention." + names[t] + ".weight"), D, dst[t], D, (int)rows, D, D);
+                q.bias = Wp(c, L + "attention.attention." + std::string(names[t]) + ".bias"); q.bias_mode = BIAS_N;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            }
+            {   // S[b,h] = (Q K^T) * hd^-0.5   (HF eager_attention_forward :153-179; softmax internals fp32)
+                GemmP q = gp(qp, D, kp, D, S, Tn, Tn, Tn, hd);
+                q.alpha = 1.0f / std::sqrt((float)hd); q.out_f32 = 1; q.nb0 = nb; q.nb1 = nh;
+                q.sA0 = (long)Tn * D; q.sA1 = hd; q.sW0 = (long)Tn * D; q.sW1 = hd; q.sC0 = (long)nh * Tn * Tn; q.sC1 = (long)Tn * Tn;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            }
+            car_launch_softmax(mode, S, Tn, P, Tpad, (long)nb * nh * Tn, Tn, 0, nullptr, 0, 0, st);
+            car_launch_transpose_pad(mode, vp, D, (long)Tn * D, vT, nb, Tn, Tpad, D, st);
+            {   // ctx[b, t, h*hd + d] = P[b,h] @ V[b,h]
+                GemmP q = gp(P, Tpad, vT, Tpad, ctx, D, Tn, hd, Tpad);
+                q.nb0 = nb; q.nb1 = nh;
+                q.sA0 = (long)nh * Tn * Tpad; q.sA1 = (long)Tn * Tpad; q.sW0 = (long)D * Tpad; q.sW1 = (long)hd * Tpad; q.sC0 = (long)Tn * D; q.sC1 = hd;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            }
+            {   // h = layer_scale1(dense(ctx)) + h   (HF :342-363)
+                GemmP q = gp(ctx, D, Wp(c, L + "attention.output.dense.weight"), D, h, D, (int)rows, D, D);
+                q.bias = Wp(c, L + "attention.output.dense.bias"); q.bias_mode = BIAS_N; q.scale = Wp(c, L + "layer_scale1.lambda1"); q.R = h; q.ldr = D;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            }
+            car_launch_layernorm(mode, h, Wp(c, L + "norm2.weight"), Wp(c, L + "norm2.bias"), y, rows, D, g.vit_ln_eps, st);
+            {   // erf-GELU MLP (HF :281-297)
+                GemmP q = gp(y, D, Wp(c, L + "mlp.fc1.weight"), D, mid, g.vit_mlp, (int)rows, g.vit_mlp, D);
+                q.bias = Wp(c, L + "mlp.fc1.bias"); q.bias_mode = BIAS_N; q.act = ACT_GELU_ERF;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+                GemmP r = gp(mid, g.vit_mlp, Wp(c, L + "mlp.fc2.weight"), g.vit_mlp, h, D, (int)rows, D, g.vit_mlp);
+                r.bias = Wp(c, L + "mlp.fc2.bias"); r.bias_mode = BIAS_N; r.scale = Wp(c, L + "layer_scale2.lambda1"); r.R = h; r.ldr = D;
+                car_launch_gemm(mode, AMODE_PLAIN, &r, st);
+            }
+        }
+        car_launch_layernorm(mode, h, Wp(c, a + "layernorm.weight"), Wp(c, a + "layernorm.bias"), y, rows, D, g.vit_ln_eps, st);
+        // drop CLS (dinov2_adapter.py:29) by addressing, then adapter_mlp (generate.py:138)
+        mlp_tanh(c, off(y, (size_t)D, e), D, (long)Tn * D, nb, n, D, "adapter_mlp.", mid, off(c->ctrl_in.p, (size_t)b0 * n * g.dim, e), g.dim, st);
+    }
+    if (out) HIPCHK(c, hipMemcpyAsync(out, c->ctrl_in.p, (size_t)B * n * g.dim * e, hipMemcpyDeviceToDevice, st));
+    fence_out(c, caller);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- decode step (one token for all b sequences)
+struct StepBufs { void *h, *xn, *qkv, *att, *mid, *mid2; float* part; float* logits; int *pos, *step, *cur; };
+
+static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b, int B, int S_max, int n_tok, int nsplit, bool use_ctrl,
+                               float cs, const SampleP& sp_tmpl, hipStream_t st) {
+    const car_config& g = c->cfg; const int mode = c->mode; const size_t e = c->esz;
+    const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, li = g.n_layer / 3;
+    const size_t kv_layer = (size_t)b * Hn * S_max * 64;
+    int nk = 0;
+    for (int l = 0; l < g.n_layer; ++l) {
+        const std::string L = "layers." + std::to_string(l) + ".";
+        {   // token gather (layer 0), control add (layers 0, n/3, 2n/3), attention_norm
+            NormP np; memset(&np, 0, sizeof(np));
+            np.h_in = sb.h; np.h_out = sb.h; np.xn = sb.xn; np.w = Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            if (l == 0) { np.emb = Wp(c, "tok_embeddings.weight"); np.idx = sb.cur; }
+            if (use_ctrl && l % li == 0 && l / li < 3) { np.add_mode = 1; np.ctrl = c->ctrl[l / li].p; np.pos = sb.pos; np.T = g.cls_token_num; np.n_tok = n_tok; np.cs = cs; }
+            car_launch_rmsnorm(mode, &np, b, st); ++nk;
+        }
+        { GemmP q = gp(sb.xn, D, Wp(c, L + "attention.wqkv.weight"), D, sb.qkv, 3 * D, b, 3 * D, D); car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk; }
+        {
+            AttnP ap; memset(&ap, 0, sizeof(ap));
+            ap.qkv = sb.qkv; ap.kcache = off(c->kv.p, (size_t)(2 * l) * kv_layer, e); ap.vcache = off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e);
+            ap.rope = c->rope; ap.pos = sb.pos; ap.emb_mask = (const unsigned char*)c->maskb.p; ap.out = sb.att; ap.part = sb.part;
+            ap.H = Hn; ap.S_max = S_max; ap.T = g.cls_token_num; ap.dim = D; ap.nsplit = nsplit;
+            car_launch_dec_attn(mode, &ap, b, st); nk += nsplit > 1 ? 2 : 1;
+        }
+        { GemmP q = gp(sb.att, D, Wp(c, L + "attention.wo.weight"), D, sb.h, D, b, D, D); q.R = sb.h; q.ldr = D; car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk; }
+        { NormP np; memset(&np, 0, sizeof(np)); np.h_in = sb.h; np.xn = sb.xn; np.w = Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps; car_launch_rmsnorm(mode, &np, b, st); ++nk; }
+        if (mode == CAR_BF16) {
+            GemmP q = gp(sb.xn, D, Wp(c, L + "feed_forward.w13.weight"), D, sb.mid, Fh, b, 2 * Fh, D); q.swiglu = 1; car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk;
+        } else {
+            GemmP q = gp(sb.xn, D, Wp(c, L + "feed_forward.w13.weight"), D, sb.mid2, 2 * Fh, b, 2 * Fh, D); car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            car_launch_swiglu(mode, sb.mid2, sb.mid, b, Fh, st); nk += 2;
+        }
+        { GemmP q = gp(sb.mid, Fh, Wp(c, L + "feed_forward.w2.weight"), Fh, sb.h, D, b, D, Fh); q.R = sb.h; q.ldr = D; car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk; }
+    }
+    { NormP np; memset(&np, 0, sizeof(np)); np.h_in = sb.h; np.xn = sb.xn; np.w = Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps; car_launch_rmsnorm(mode, &np, b, st); ++nk; }
+    {   // logits: bf16-rounded then widened (gpt_t2i.py:470) — rnd() in the epilogue, fp32 storage
+        GemmP q = gp(sb.xn, D, Wp(c, "output.weight"), D, sb.logits, g.vocab_size, b, g.vocab_size, D); q.out_f32 = 1;
+        car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk;
+    }
+    car_launch_advance(sb.pos, sb.step, st); ++nk;      // pos = T+i+1 consumed next step; step indexes the token being sampled
+    SampleP sp = sp_tmpl; car_launch_sample_greedy(&sp, st); ++nk;
+    c->n_dec_kernels = nk;
+    (void)B;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- generate
+extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype, const int64_t* emb_mask, int32_t B, int32_t n_new,
+                            int32_t use_control, const car_sampling* sp, int32_t* out_tokens, const int32_t* forced_tokens,
+                            float* logits_out, void* stream_) {
+    if (!c) return -1;
+    if (!c->finalized) FAIL(c, "car_generate: call car_finalize_weights first");
+    if (!text_emb || !sp || !out_tokens || B <= 0 || n_new <= 0) FAIL(c, "car_generate: bad arguments");
+    if (text_dtype != CAR_DT_F32 && text_dtype != CAR_DT_BF16) FAIL(c, "car_generate: text dtype must be F32 or BF16");
+    const car_config& g = c->cfg;
+    if (sp->sample_logits) FAIL(c, "car_generate: stochastic sampling (sample_logits=True) is not built yet; greedy only");
+    if (sp->top_p < 1.0f) { /* greedy: filtering never changes the arg-max */ }
+    const int T = g.cls_token_num;
+    if (n_new > g.block_size) FAIL(c, "car_generate: max_new_tokens %d exceeds block_size %d (rope table rows, gpt_t2i.py:454)", n_new, g.block_size);
+    if (use_control && (c->ctrl_B != B || c->ctrl_ntok < n_new)) FAIL(c, "car_generate: control tokens cached for B=%d n=%d, requested B=%d n_new=%d", c->ctrl_B, c->ctrl_ntok, B, n_new);
+    const bool use_cfg = sp->cfg_scale > 1.0f;
+    const int b = use_cfg ? 2 * B : B;
+    const float cs = use_cfg ? sp->control_strength : 1.0f;         // generate.py:87-92: strength ignored when cfg <= 1
+    const int S_max = (int)rup(T + n_new, 8);                       // gpt_t2i.py:395
+    const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, V = g.vocab_size, n_tok = c->ctrl_ntok, li = g.n_layer / 3;
+    const int mode = c->mode; const size_t e = c->esz;
+    hipStream_t caller = (hipStream_t)stream_, st = c->stream;
+    const int Tpad = (int)rup(T, 32);
+
+    // ---- buffers
+    const size_t kv_layer = (size_t)b * Hn * S_max * 64;
+    NEED(c, c->kv, (size_t)g.n_layer * 2 * kv_layer * e);
+    const long rowsP = (long)b * T;
+    NEED(c, c->ws[0], (size_t)b * T * g.caption_dim * e);                     // text input (cond | uncond)
+    NEED(c, c->ws[1], (size_t)rowsP * D * e);                                 // h (prefill)
+    NEED(c, c->ws[2], (size_t)rowsP * D * e);                                 // xn
+    NEED(c, c->ws[3], (size_t)rowsP * 3 * D * e);                             // qkv
+    NEED(c, c->ws[4], (size_t)b * Hn * T * T * 4);                            // S
+    NEED(c, c->ws[5], (size_t)b * Hn * T * Tpad * e);                         // P
+    NEED(c, c->ws[6], (size_t)b * D * Tpad * e);                              // V^T
+    NEED(c, c->ws[7], (size_t)rowsP * (mode == CAR_BF16 ? Fh : 3 * Fh) * e);  // ffn mid (+ interleaved w13 out in exact mode)
+    NEED(c, c->ws[8], (size_t)rowsP * D * e);                                 // attention out
+    NEED(c, c->ws[9], (size_t)b * V * 4);                                     // logits fp32
+    int nsplit = 1;
+    { const int wg = b * Hn; while (wg * nsplit < 1024 && nsplit < 16) nsplit *= 2; }
+    NEED(c, c->ws[10], (size_t)b * Hn * nsplit * 66 * 4);                     // split-KV partials
+    NEED(c, c->ws[11], (size_t)B * (use_control ? n_tok : 1) * D * e);        // condition_mlp output / mlp mid
+    NEED(c, c->scal, (size_t)(8 + b) * 4);
+    NEED(c, c->tok_out, (size_t)B * n_new * 4);
+    NEED(c, c->maskb, (size_t)b * T);
+    for (int k = 0; k < 3; ++k) if (use_control) NEED(c, c->ctrl[k], (size_t)b * n_tok * D * e);
+
+    fence_in(c, caller);
+    HIPCHK(c, hipEventRecord(c->ev_t0, st));
+    // The reference zero-fills fresh KVCache buffers every call (gpt_t2i.py:223-225, :391-405); slots that
+    // were never written are always masked there and never read here (dec_attn walks only valid rows), so
+    // no memset is needed.
+    // text-pad mask -> uint8 [b, T] (both CFG halves share it, generate.py:188)
+    {
+        std::vector<unsigned char> mk((size_t)b * T, 1);
+        if (emb_mask) {
+            std::vector<int64_t> hm((size_t)B * T);
+            HIPCHK(c, hipStreamSynchronize(st));      // inputs ready (one-time, outside the token loop)
+            HIPCHK(c, hipMemcpy(hm.data(), emb_mask, hm.size() * 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < b; ++i) for (int t = 0; t < T; ++t) mk[(size_t)i * T + t] = hm[(size_t)(i % B) * T + t] != 0;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->maskb.p, mk.data(), mk.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));          // mk is a stack-lifetime host buffer
+    }
+    int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 8;
+    {
+        int init[2] = {T, 0};    // after prefill the first decode step runs at input_pos = T, sampling token index 1
+        HIPCHK(c, hipMemcpyAsync(pos, init, 8, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+
+    // ---- D. text prefix embed: cls_embedding.cap_proj (gpt_t2i.py:435), uncond rows = uncond_embedding (generate.py:157)
+    void *text = c->ws[0].p, *h = c->ws[1].p, *xn = c->ws[2].p, *qkv = c->ws[3].p, *P = c->ws[5].p, *vT = c->ws[6].p, *mid = c->ws[7].p, *att = c->ws[8].p;
+    float* S = (float*)c->ws[4].p; float* logits = (float*)c->ws[9].p;
+    car_launch_build_text(mode, text_emb, text_dtype, Wp(c, "cls_embedding.uncond_embedding"), text, B, (long)T * g.caption_dim, use_cfg, st);
+    mlp_tanh(c, text, g.caption_dim, 0, 1, (int)rowsP, g.caption_dim, "cls_embedding.cap_proj.", xn, h, D, st);
+    // ---- C. control tokens: condition_mlp then 3 condition_layers, cached for the whole call (gpt_t2i.py:437-442)
+    if (use_control) {
+        const int Mc = B * n_tok;
+        void* ce = c->ws[11].p;
+        // scratch for the MLP hidden activations: reuse the (idle) KV area? no — use ws[7]/ws[3] sized for prefill; allocate via ws[4] if needed
+        DevBuf& scratch = c->ws[4];
+        NEED(c, scratch, (size_t)Mc * D * e > (size_t)b * Hn * T * T * 4 ? (size_t)Mc * D * e : (size_t)b * Hn * T * T * 4);
+        S = (float*)c->ws[4].p;
+        mlp_tanh(c, c->ctrl_in.p, D, 0, 1, Mc, D, "condition_mlp.cap_proj.", scratch.p, ce, D, st);
+        for (int k = 0; k < 3; ++k) {
+            if (use_cfg) HIPCHK(c, hipMemsetAsync(off(c->ctrl[k].p, (size_t)Mc * D, e), 0, (size_t)Mc * D * e, st));   // uncond half: MLP(0) = 0 exactly
+            mlp_tanh(c, ce, D, 0, 1, Mc, D, "condition_layers." + std::to_string(k) + ".", scratch.p, c->ctrl[k].p, D, st);
+        }
+    }
+    // ---- E. prefill over the T prefix rows (gpt_t2i.py:446-470)
+    for (int l = 0; l < g.n_layer; ++l) {
+        const std::string L = "layers." + std::to_string(l) + ".";
+        {
+            NormP np; memset(&np, 0, sizeof(np));
+            np.h_in = h; np.h_out = h; np.xn = xn; np.w = Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            if (use_control && l % li == 0 && l / li < 3) { np.add_mode = 2; np.ctrl = c->ctrl[l / li].p; np.T = T; np.n_tok = n_tok; np.cs = cs; }
+            car_launch_rmsnorm(mode, &np, rowsP, st);
+        }
+        { GemmP q = gp(xn, D, Wp(c, L + "attention.wqkv.weight"), D, qkv, 3 * D, (int)rowsP, 3 * D, D); car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
+        car_launch_prefill_rope_kv(mode, qkv, off(c->kv.p, (size_t)(2 * l) * kv_layer, e), off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e), c->rope, b, T, Hn, D, S_max, st);
+        {
+            GemmP q = gp(qkv, 3 * D, off(qkv, (size_t)D, e), 3 * D, S, T, T, T, 64);
+            q.alpha = 0.125f; q.out_f32 = 1; q.nb0 = b; q.nb1 = Hn;
+            q.sA0 = (long)T * 3 * D; q.sA1 = 64; q.sW0 = (long)T * 3 * D; q.sW1 = 64; q.sC0 = (long)Hn * T * T; q.sC1 = (long)T * T;
+            car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+        }
+        car_launch_softmax(mode, S, T, P, Tpad, (long)b * Hn * T, T, 1, (const unsigned char*)c->maskb.p, T, Hn, st);
+        car_launch_transpose_pad(mode, off(qkv, (size_t)2 * D, e), 3 * D, (long)T * 3 * D, vT, b, T, Tpad, D, st);
+        {
+            GemmP q = gp(P, Tpad, vT, Tpad, att, D, T, 64, Tpad);
+            q.nb0 = b; q.nb1 = Hn;
+            q.sA0 = (long)Hn * T * Tpad; q.sA1 = (long)T * Tpad; q.sW0 = (long)D * Tpad; q.sW1 = (long)64 * Tpad; q.sC0 = (long)T * D; q.sC1 = 64;
+            car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+        }
+        { GemmP q = gp(att, D, Wp(c, L + "attention.wo.weight"), D, h, D, (int)rowsP, D, D); q.R = h; q.ldr = D; car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
+        { NormP np; memset(&np, 0, sizeof(np)); np.h_in = h; np.xn = xn; np.w = Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps; car_launch_rmsnorm(mode, &np, rowsP, st); }
+        if (mode == CAR_BF16) {
+            GemmP q = gp(xn, D, Wp(c, L + "feed_forward.w13.weight"), D, mid, Fh, (int)rowsP, 2 * Fh, D); q.swiglu = 1; car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+        } else {
+            void* mid2 = off(mid, (size_t)rowsP * Fh, e);
+            GemmP q = gp(xn, D, Wp(c, L + "feed_forward.w13.weight"), D, mid2, 2 * Fh, (int)rowsP, 2 * Fh, D); car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            car_launch_swiglu(mode, mid2, mid, rowsP, Fh, st);
+        }
+        { GemmP q = gp(mid, Fh, Wp(c, L + "feed_forward.w2.weight"), Fh, h, D, (int)rowsP, D, Fh); q.R = h; q.ldr = D; car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
+    }
+    // final norm + logits for the LAST prefix row only (generate.py:60 samples logits[:, -1])
+    { NormP np; memset(&np, 0, sizeof(np)); np.h_in = h; np.xn = xn; np.w = Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps; car_launch_rmsnorm(mode, &np, rowsP, st); }
+    { GemmP q = gp(off(xn, (size_t)(T - 1) * D, e), (long)T * D, Wp(c, "output.weight"), D, logits, V, b, V, D); q.out_f32 = 1; car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
+    SampleP spp; memset(&spp, 0, sizeof(spp));
+    spp.logits = logits; spp.B = B; spp.V = V; spp.use_cfg = use_cfg; spp.cfg_scale = sp->cfg_scale; spp.cfg_interval = sp->cfg_interval;
+    spp.step_ptr = step; spp.n_new = n_new; spp.out_tokens = (int*)c->tok_out.p; spp.cur_tok = cur; spp.forced = forced_tokens; spp.logits_out = logits_out;
+    car_launch_sample_greedy(&spp, st);
+    HIPCHK(c, hipEventRecord(c->ev_t1, st));
+
+    // ---- F/G. decode loop: one captured step, replayed n_new-1 times (pos/step/token live on the device)
+    StepBufs sb;
+    sb.h = h; sb.xn = xn; sb.qkv = qkv; sb.att = att; sb.mid = mid; sb.mid2 = off(mid, (size_t)b * Fh, e);
+    sb.part = (float*)c->ws[10].p; sb.logits = logits; sb.pos = pos; sb.step = step; sb.cur = cur;
+    const int nsteps = n_new - 1;
+    c->stats.graph_used = 0;
+    if (nsteps > 0) {
+        char keyb[256];
+        snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%p|%p", b, B, S_max, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
+                 c->ctrl[0].p, c->maskb.p, c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, (const void*)forced_tokens, (void*)logits_out);
+        const std::string key(keyb);
+        bool graph_ok = true;
+        if (!c->gexec || c->gkey != key) {
+            if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_ok = false; (void)hipGetLastError(); }
+            if (graph_ok) {
+                enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st);
+                if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) { graph_ok = false; (void)hipGetLastError(); }
+            }
+            if (graph_ok && hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0) != hipSuccess) { graph_ok = false; c->gexec = nullptr; (void)hipGetLastError(); }
+            if (graph) (void)hipGraphDestroy(graph);
+            if (graph_ok) c->gkey = key;
+        }
+        if (graph_ok) {
+            for (int i = 0; i < nsteps; ++i) HIPCHK(c, hipGraphLaunch(c->gexec, st));
+            c->stats.graph_used = 1;
+        } else {
+            for (int i = 0; i < nsteps; ++i) enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st);
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev_t2, st));
+    HIPCHK(c, hipMemcpyAsync(out_tokens, c->tok_out.p, (size_t)B * n_new * 4, hipMemcpyDeviceToDevice, st));
+    fence_out(c, caller);
+    HIPCHK(c, hipGetLastError());
+    // stats (algorithmic bytes: DESIGN.md §4 / SURVEY.md §8d)
+    {
+        c->stats.decode_steps = nsteps;
+        c->stats.decode_kernels_per_step = c->n_dec_kernels;
+        const double wbytes = ((double)g.n_layer * ((double)3 * D * D + (double)D * D + 3.0 * (double)Fh * D + 2.0 * D) + D + (double)V * D) * (double)e;
+        double kvb = 0;
+        for (int i = 0; i < nsteps; ++i) { const double p = T + i; kvb += 2.0 * g.n_layer * D * (double)e * (p + 1); }
+        c->stats.decode_algo_bytes = (int64_t)(wbytes * nsteps + kvb * b);
+    }
+    return 0;
+}
+
+extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
+    if (!c || !out) return -1;
+    float ms = 0.f;
+    (void)hipEventSynchronize(c->ev_t2);
+    if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) == hipSuccess) c->stats.prefill_ms = ms; else (void)hipGetLastError();
+    if (hipEventElapsedTime(&ms, c->ev_t1, c->ev_t2) == hipSuccess) c->stats.decode_ms = ms; else (void)hipGetLastError();
+    *out = c->stats;
+    return 0;
+}
+
+extern "C" int car_debug_control_tokens(car_ctx* c, int32_t k, float* host_out, int64_t max_elems) {
+    if (!c || k < 0 || k > 2 || !host_out) return -1;
+    (void)hipStreamSynchronize(c->stream);
+    const size_t n = c->ctrl[k].cap ? (size_t)max_elems : 0;
+    if (!n) FAIL(c, "no control tokens cached");
+    if (c->mode == CAR_F32) { HIPCHK(c, hipMemcpy(host_out, c->ctrl[k].p, n * 4, hipMemcpyDeviceToHost)); }
+    else { std::vector<bf16_t> hb(n); HIPCHK(c, hipMemcpy(hb.data(), c->ctrl[k].p, n * 2, hipMemcpyDeviceToHost)); for (size_t i = 0; i < n; ++i) host_out[i] = bf2f(hb[i]); }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- VQ decode
+extern "C" int car_vq_decode(car_ctx* c, const int32_t* tokens, int32_t B, int32_t hh, int32_t ww, float* out_nchw, void* stream_) {
+    if (!c) return -1;
+    if (!c->finalized) FAIL(c, "car_vq_decode: call car_finalize_weights first");
+    if (!Wp(c, "quantize.embedding.weight")) FAIL(c, "car_vq_decode: VQ weights were not loaded into this context");
+    if (!tokens || !out_nchw || B <= 0 || hh <= 0 || ww <= 0) FAIL(c, "car_vq_decode: bad arguments");
+    const car_config& g = c->cfg; const int mode = c->mode; const size_t e = c->esz;
+    hipStream_t caller = (hipStream_t)stream_, st = c->stream;
+    int last_c = 0;
+    const std::vector<VqItem> layout = vq_layout(g, &last_c);
+    const int nup = g.vq_n_mult - 1, Hf = hh << nup, Wf = ww << nup;
+    // largest activation (elements per image): track through the layout
+    size_t max_el = 0; { int ch = g.vq_ch * g.vq_ch_mult[g.vq_n_mult - 1]; size_t hw = (size_t)hh * ww; max_el = hw * (ch > g.z_channels ? ch : g.z_channels);
+        for (auto& it : layout) { if (it.kind == 2) hw *= 4; size_t cc = it.kind == 0 ? (it.cin > it.cout ? it.cin : it.cout) : it.cin; if (hw * cc > max_el) max_el = hw * cc; } }
+    // chunk the batch so that ~4 live activation buffers stay below ~8 GiB
+    int CH = B; while (CH > 1 && (size_t)CH * max_el * e * 4 > ((size_t)8 << 30)) CH = (CH + 1) / 2;
+    const size_t abytes = (size_t)CH * max_el * e;
+    for (int i = 0; i < 4; ++i) NEED(c, c->ws[i], abytes);
+    const int HW0 = hh * ww, C0 = g.vq_ch * g.vq_ch_mult[g.vq_n_mult - 1];
+    const int HWp = (int)rup(HW0, 32);
+    NEED(c, c->ws[4], (size_t)CH * HW0 * HW0 * 4);            // attention scores fp32
+    NEED(c, c->ws[5], (size_t)CH * HW0 * HWp * e);            // P
+    NEED(c, c->ws[6], (size_t)CH * C0 * HWp * e);             // V^T
+    NEED(c, c->ws[7], (size_t)CH * 3 * HW0 * C0 * e);         // q, k, v
+    NEED(c, c->ws[8], (size_t)CH * ((size_t)(Hf * Wf + 255) / 256) * 2 * 512 * 4 + 1024);   // GN partials (C <= 512)
+    NEED(c, c->ws[9], (size_t)CH * 32 * 2 * 4 + 64);          // GN stats
+    fence_in(c, caller);
+    auto conv3 = [&](const void* x, void* y, const std::string& name, int nb, int Ho, int Wo, int Cin, int Cout, int ups, const void* R) {
+        GemmP q = gp(x, 0, Wp(c, name + ".weight"), 9 * (long)Cin, y, Cout, nb * Ho * Wo, Cout, 9 * Cin);
+        q.bias = Wp(c, name + ".bias"); q.bias_mode = BIAS_N; q.Ho = Ho; q.Wo = Wo; q.Cin = Cin; q.ups = ups; q.R = R; q.ldr = Cout;
+        car_launch_gemm(mode, AMODE_CONV3, &q, st);
+    };
+    auto conv1 = [&](const void* x, void* y, const std::string& name, int M, int Cin, int Cout, const void* R) {
+        GemmP q = gp(x, Cin, Wp(c, name + ".weight"), Cin, y, Cout, M, Cout, Cin);
+        q.bias = Wp(c, name + ".bias"); q.bias_mode = BIAS_N; q.R = R; q.ldr = Cout;
+        car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+    };
+    auto gn = [&](const void* x, void* y, const std::string& name, int nb, int HW, int C, int swish) {
+        car_launch_groupnorm(mode, x, Wp(c, name + ".weight"), Wp(c, name + ".bias"), y, (float*)c->ws[8].p, (float*)c->ws[9].p, nb, HW, C, 32, g.gn_eps, swish, st);
+    };
+    for (int b0 = 0; b0 < B; b0 += CH) {
+        const int nb = (B - b0) < CH ? (B - b0) : CH;
+        void *x = c->ws[0].p, *t1 = c->ws[1].p, *t2 = c->ws[2].p, *t3 = c->ws[3].p;
+        int Hc = hh, Wc = ww;
+        // get_codebook_entry + post_quant_conv (vq_model.py:262-277, :49) -> NHWC
+        car_launch_vq_lookup(mode, tokens + (size_t)b0 * HW0, (const float*)Wp(c, "quantize.embedding.weight"), (const float*)Wp(c, "post_quant_conv.weight"),
+                             (const float*)Wp(c, "post_quant_conv.bias"), t1, (long)nb * HW0, g.codebook_dim, g.z_channels, g.codebook_size, st);
+        conv3(t1, x, "decoder.conv_in", nb, Hc, Wc, g.z_channels, C0, 0, nullptr);
+        for (auto& it : layout) {
+            const int HW = Hc * Wc;
+            if (it.kind == 0) {           // ResnetBlock (vq_model.py:300-315)
+                gn(x, t1, it.name + ".norm1", nb, HW, it.cin, 1);
+                conv3(t1, t2, it.name + ".conv1", nb, Hc, Wc, it.cin, it.cout, 0, nullptr);
+                gn(t2, t1, it.name + ".norm2", nb, HW, it.cout, 1);
+                if (it.cin != it.cout) { conv1(x, t3, it.name + ".nin_shortcut", nb * HW, it.cin, it.cout, nullptr); conv3(t1, t2, it.name + ".conv2", nb, Hc, Wc, it.cout, it.cout, 0, t3); std::swap(x, t2); }
+                else { conv3(t1, x, it.name + ".conv2", nb, Hc, Wc, it.cout, it.cout, 0, x); }
+            } else if (it.kind == 1) {    // AttnBlock (vq_model.py:328-352): single head over HW positions
+                const int C = it.cin; const int Tp = (int)rup(HW, 32);
+                gn(x, t1, it.name + ".norm", nb, HW, C, 0);
+                void* qb = c->ws[7].p; void* kb = off(qb, (size_t)nb * HW * C, e); void* vb = off(qb, (size_t)2 * nb * HW * C, e);
+                conv1(t1, qb, it.name + ".q", nb * HW, C, C, nullptr); conv1(t1, kb, it.name + ".k", nb * HW, C, C, nullptr); conv1(t1, vb, it.name + ".v", nb * HW, C, C, nullptr);
+                float* S = (float*)c->ws[4].p;
+                { GemmP q = gp(qb, C, kb, C, S, HW, HW, HW, C); q.alpha = 1.0f / std::sqrt((float)C); q.out_f32 = 1; q.nb0 = nb; q.sA0 = (long)HW * C; q.sW0 = (long)HW * C; q.sC0 = (long)HW * HW; car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
+                car_launch_softmax(mode, S, HW, c->ws[5].p, Tp, (long)nb * HW, HW, 0, nullptr, 0, 0, st);
+                car_launch_transpose_pad(mode, vb, C, (long)HW * C, c->ws[6].p, nb, HW, Tp, C, st);
+                { GemmP q = gp(c->ws[5].p, Tp, c->ws[6].p, Tp, t2, C, HW, C, Tp); q.nb0 = nb; q.sA0 = (long)HW * Tp; q.sW0 = (long)C * Tp; q.sC0 = (long)HW * C; car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
+                conv1(t2, x, it.name + ".proj_out", nb * HW, C, C, x);
+            } else {                      // Upsample: nearest x2 folded into the conv gather (vq_model.py:375-379)
+                Hc *= 2; Wc *= 2;
+                conv3(x, t1, it.name + ".conv", nb, Hc, Wc, it.cin, it.cin, 1, nullptr);
+                std::swap(x, t1);
+            }
+        }
+        gn(x, t1, "decoder.norm_out", nb, Hc * Wc, last_c, 1);
+        car_launch_conv_out(mode, t1, Wp(c, "decoder.conv_out.weight"), (const float*)Wp(c, "decoder.conv_out.bias"), out_nchw + (size_t)b0 * 3 * Hf * Wf, nb, Hc, Wc, last_c, st);
+    }
+    fence_out(c, caller);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,416 @@
+// ops.hip — bandwidth-bound helper kernels of the path: norms, softmax, resize/patchify,
+// GroupNorm+swish on NHWC, codebook lookup, final RGB conv, embedding gathers, greedy sampling.
+// Kernels are templated on the element type T (float = exact mode, bf16_t = fast mode), take
+// untyped pointers, reduce in fp32 with wave64 shuffles in a fixed order (deterministic), and
+// round where the reference's torch ops round.
+#include "car_common.h"
+
+#define LAUNCH_T(mode, KERNEL, grid, block, st, ...)                                          \
+    do {                                                                                      \
+        if ((mode) == 1) hipLaunchKernelGGL((KERNEL<bf16_t>), grid, block, 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<float>), grid, block, 0, st, __VA_ARGS__);            \
+    } while (0)
+
+// ------------------------------------------------------------------ dtype conversion (inputs arrive as f32 or bf16)
+template <typename T>
+__global__ void convert_kernel(const void* src, int src_dtype, void* dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float v = src_dtype == 1 ? bf2f(((const bf16_t*)src)[i]) : ((const float*)src)[i];
+        ET<T>::st((T*)dst + i, v);
+    }
+}
+extern "C" void car_launch_convert(int mode, const void* src, int src_dtype, void* dst, long n, hipStream_t st) {
+    int g = (int)((n + 255) / 256); if (g > 4096) g = 4096; if (g < 1) g = 1;
+    LAUNCH_T(mode, convert_kernel, dim3(g), dim3(256), st, src, src_dtype, dst, n);
+}
+
+// text input: rows [0,B) = cond * 1 (already masked by the caller), rows [B,2B) = uncond_embedding
+// (reference generate.py:156-158)
+template <typename T>
+__global__ void build_text_kernel(const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg) {
+    const long n = (long)(use_cfg ? 2 * B : B) * per;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const long b = i / per, r = i - b * per;
+        float v;
+        if (b < B) v = src_dtype == 1 ? bf2f(((const bf16_t*)cond)[i]) : ((const float*)cond)[i];
+        else v = ET<T>::rnd(0.f + ET<T>::ld((const T*)uncond + r));
+        ET<T>::st((T*)dst + i, v);
+    }
+}
+extern "C" void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg, hipStream_t st) {
+    LAUNCH_T(mode, build_text_kernel, dim3(2048), dim3(256), st, cond, src_dtype, uncond, dst, B, per, use_cfg);
+}
+
+// ------------------------------------------------------------------ LayerNorm (HF Dinov2Layer norm1/norm2/layernorm, eps 1e-6)
+template <typename T>
+__global__ __launch_bounds__(128) void layernorm_kernel(const void* x_, const void* w_, const void* b_, void* y_, int D, float eps) {
+    __shared__ float sm[20];
+    const T* x = (const T*)x_ + (long)blockIdx.x * D; T* y = (T*)y_ + (long)blockIdx.x * D;
+    const T* w = (const T*)w_; const T* b = (const T*)b_;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) s += ET<T>::ld(x + i);
+    const float mean = block_sum(s, sm) / D;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) { float d = ET<T>::ld(x + i) - mean; v += d * d; }
+    const float rstd = rsqrtf(block_sum(v, sm) / D + eps);
+    for (int i = threadIdx.x; i < D; i += blockDim.x)
+        ET<T>::st(y + i, (ET<T>::ld(x + i) - mean) * rstd * ET<T>::ld(w + i) + ET<T>::ld(b + i));
+}
+extern "C" void car_launch_layernorm(int mode, const void* x, const void* w, const void* b, void* y, long rows, int D, float eps, hipStream_t st) {
+    LAUNCH_T(mode, layernorm_kernel, dim3(rows), dim3(128), st, x, w, b, y, D, eps);
+}
+
+// ------------------------------------------------------------------ RMSNorm with optional token gather and control add
+// reference: gpt_t2i.py:193-198 (norm), :445 (tok_embeddings gather), :463/:466 (control add)
+//   row r:  v = gather ? emb[idx[r]] : h_in[r]
+//           add_mode 1 (decode):  v = rnd(v + rnd(cs * ctrl[r, *pos - T + 1]))
+//           add_mode 2 (prefill): same with control token 0, only on rows r % T == T-1 (ctrl batch = r / T)
+//           h_out[r] = v (if h_out);  xn[r] = rnd(rnd(v * rsqrt(mean(v^2)+eps)) * w)
+struct NormP {
+    const void* h_in; const void* emb; const int* idx; void* h_out; void* xn; const void* w;
+    const void* ctrl; const int* pos; int add_mode; int T; int n_tok; float cs;
+    int D; float eps;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(NormP p) {
+    __shared__ float sm[20];
+    extern __shared__ float rowbuf[];   // D floats
+    const long r = blockIdx.x;
+    const int D = p.D;
+    const T* src = p.idx ? (const T*)p.emb + (long)p.idx[r] * D : (const T*)p.h_in + r * D;
+    const T* add = nullptr;
+    if (p.add_mode == 1) add = (const T*)p.ctrl + (r * p.n_tok + (*p.pos - p.T + 1)) * D;
+    else if (p.add_mode == 2 && (r % p.T) == p.T - 1) add = (const T*)p.ctrl + ((r / p.T) * (long)p.n_tok) * D;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        float v = ET<T>::ld(src + i);
+        if (add) v = ET<T>::rnd(v + ET<T>::rnd(p.cs * ET<T>::ld(add + i)));
+        rowbuf[i] = v;
+        ss += v * v;
+    }
+    const float rstd = rsqrtf(block_sum(ss, sm) / D + p.eps);
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        const float v = rowbuf[i];
+        if (p.h_out) ET<T>::st((T*)p.h_out + r * D + i, v);
+        ET<T>::st((T*)p.xn + r * D + i, ET<T>::rnd(v * rstd) * ET<T>::ld((const T*)p.w + i));
+    }
+}
+extern "C" void car_launch_rmsnorm(int mode, const NormP* p, long rows, hipStream_t st) {
+    if (mode == 1) hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, dim3(rows), dim3(256), p->D * sizeof(float), st, *p);
+    else hipLaunchKernelGGL(rmsnorm_kernel<float>, dim3(rows), dim3(256), p->D * sizeof(float), st, *p);
+}
+
+// ------------------------------------------------------------------ row softmax  S fp32 [rows, lds] -> P T [rows, ldp] (zero padded)
+// mask_mode 0: none (ViT, VQ attention).  mask_mode 1: LlamaGen prefill mask (generate.py:184-193):
+//   rows ordered (b, head, i); key j allowed iff j <= i and (emb_mask[b, j] != 0 or j == i).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_kernel(const float* S, long lds, void* P_, long ldp, int ncols, int mask_mode,
+                                                      const unsigned char* emb_mask, int Tq, int n_head) {
+    __shared__ float sm[20];
+    const long r = blockIdx.x;
+    const float* s = S + r * lds; T* P = (T*)P_ + r * ldp;
+    const int i = mask_mode ? (int)(r % Tq) : 0;
+    const unsigned char* mk = mask_mode ? emb_mask + (r / Tq / n_head) * Tq : nullptr;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < ncols; j += blockDim.x) {
+        bool ok = !mask_mode || (j <= i && (mk[j] || j == i));
+        if (ok) mx = fmaxf(mx, s[j]);
+    }
+    mx = block_max(mx, sm);
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < ncols; j += blockDim.x) {
+        bool ok = !mask_mode || (j <= i && (mk[j] || j == i));
+        if (ok) sum += expf(s[j] - mx);
+    }
+    sum = block_sum(sum, sm);
+    const float inv = 1.0f / sum;
+    for (int j = threadIdx.x; j < ldp; j += blockDim.x) {
+        float v = 0.f;
+        if (j < ncols) { bool ok = !mask_mode || (j <= i && (mk[j] || j == i)); if (ok) v = expf(s[j] - mx) * inv; }
+        ET<T>::st(P + j, v);
+    }
+}
+extern "C" void car_launch_softmax(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, int mask_mode,
+                                   const unsigned char* emb_mask, int Tq, int n_head, hipStream_t st) {
+    LAUNCH_T(mode, softmax_kernel, dim3(rows), dim3(256), st, S, lds, P, ldp, ncols, mask_mode, emb_mask, Tq, n_head);
+}
+
+// ------------------------------------------------------------------ resize + patch unfold (dinov2_adapter.py:16-24 + HF patch conv as matmul)
+// out[b, gy*gw+gx, c*p*p + py*p + px] = resized[b, c, gy*p+py, gx*p+px], zero padded to Kpad.
+// nearest: iy/ix hold source indices.  bicubic: iy/ix hold 4 clamped indices per output index, wy/wx 4 weights.
+template <typename T>
+__global__ void patchify_kernel(const void* img, int img_dtype, void* out_, int B, int H, int W, int gh, int gw, int p, int Kpad,
+                                int bicubic, const int* iy, const int* ix, const float* wy, const float* wx) {
+    const long total = (long)B * gh * gw * Kpad;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int pp = p * p;
+    for (; i < total; i += stride) {
+        const int k = (int)(i % Kpad); const long t = i / Kpad;
+        float v = 0.f;
+        if (k < 3 * pp) {
+            const int c = k / pp, py = (k % pp) / p, px = k % p;
+            const int gx = (int)(t % gw), gy = (int)((t / gw) % gh), b = (int)(t / ((long)gw * gh));
+            const int oy = gy * p + py, ox = gx * p + px;
+            const long base = ((long)b * 3 + c) * H * W;
+            auto ld = [&](int y, int x) -> float {
+                return img_dtype == 1 ? bf2f(((const bf16_t*)img)[base + (long)y * W + x]) : ((const float*)img)[base + (long)y * W + x];
+            };
+            if (!bicubic) v = ld(iy[oy], ix[ox]);
+            else {
+                // x first, then y (ATen nested cubic_interp1d); fp32
+                float acc = 0.f;
+                for (int a = 0; a < 4; ++a) {
+                    const int yy = iy[oy * 4 + a];
+                    float row = 0.f;
+                    for (int q = 0; q < 4; ++q) row += ld(yy, ix[ox * 4 + q]) * wx[ox * 4 + q];
+                    acc += row * wy[oy * 4 + a];
+                }
+                v = img_dtype == 1 ? bf2f(f2bf(acc)) : acc;   // interpolate returns the input dtype
+            }
+        }
+        ET<T>::st((T*)out_ + i, v);
+    }
+}
+extern "C" void car_launch_patchify(int mode, const void* img, int img_dtype, void* out, int B, int H, int W, int gh, int gw, int p, int Kpad,
+                                    int bicubic, const int* iy, const int* ix, const float* wy, const float* wx, hipStream_t st) {
+    LAUNCH_T(mode, patchify_kernel, dim3(4096), dim3(256), st, img, img_dtype, out, B, H, W, gh, gw, p, Kpad, bicubic, iy, ix, wy, wx);
+}
+
+// h[b,0] = cls + pos[0];  h[b,1+t] = tok[b,t] + pos[1+t]      (HF Dinov2Embeddings.forward :97-113)
+template <typename T>
+__global__ void vit_assemble_kernel(const void* tok_, const void* cls_, const void* pos_, void* h_, int B, int n, int D) {
+    const long total = (long)B * (n + 1) * D;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int d = (int)(i % D); const long r = i / D; const int t = (int)(r % (n + 1)); const long b = r / (n + 1);
+        float v = t == 0 ? ET<T>::ld((const T*)cls_ + d) : ET<T>::ld((const T*)tok_ + (b * n + t - 1) * D + d);
+        ET<T>::st((T*)h_ + i, v + ET<T>::ld((const T*)pos_ + (long)t * D + d));
+    }
+}
+extern "C" void car_launch_vit_assemble(int mode, const void* tok, const void* cls, const void* pos, void* h, int B, int n, int D, hipStream_t st) {
+    LAUNCH_T(mode, vit_assemble_kernel, dim3(2048), dim3(256), st, tok, cls, pos, h, B, n, D);
+}
+
+// ------------------------------------------------------------------ GroupNorm(32, eps) [+ swish] on NHWC (vq_model.py:355-363)
+// stage 1: per (b, pixel-chunk) per-channel partial sums (coalesced full-row reads); stage 2: fixed-order
+// reduction to (mean, rstd) per (b, group) in double; stage 3: apply.
+#define GN_CHUNK 256   // pixels per block in stage 1
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const void* x_, float* part, int HW, int C) {
+    extern __shared__ float sh[];            // [2][256] then per-channel accumulators [2][C]
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const T* x = (const T*)x_ + (long)b * HW * C;
+    const int p0 = chunk * GN_CHUNK, p1 = min(HW, p0 + GN_CHUNK);
+    // thread t owns channel (t % C) if C <= 256 else loops; pixels strided by 256 / C
+    float* accS = sh; float* accQ = sh + C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { accS[c] = 0.f; accQ[c] = 0.f; }
+    __syncthreads();
+    if (C <= 256) {
+        const int c = threadIdx.x % C, slot = threadIdx.x / C, nslot = 256 / C;
+        float s = 0.f, q = 0.f;
+        for (int p = p0 + slot; p < p1; p += nslot) { float v = ET<T>::ld(x + (long)p * C + c); s += v; q += v * v; }
+        // reduce over slots in fixed order via LDS staging
+        float* stS = sh + 2 * C; float* stQ = stS + 256;
+        stS[threadIdx.x] = s; stQ[threadIdx.x] = q;
+        __syncthreads();
+        if (slot == 0) {
+            for (int k = 1; k < nslot; ++k) { s += stS[k * C + c]; q += stQ[k * C + c]; }
+            accS[c] = s; accQ[c] = q;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float s = 0.f, q = 0.f;
+            for (int p = p0; p < p1; ++p) { float v = ET<T>::ld(x + (long)p * C + c); s += v; q += v * v; }
+            accS[c] = s; accQ[c] = q;
+        }
+    }
+    __syncthreads();
+    float* o = part + ((long)b * nchunk + chunk) * 2 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { o[c] = accS[c]; o[C + c] = accQ[c]; }
+}
+__global__ void gn_finalize_kernel(const float* part, float* stats, int nchunk, int C, int G, int HW, float eps) {
+    const int b = blockIdx.x, g = threadIdx.x;
+    if (g >= G) return;
+    const int cpg = C / G;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const float* o = part + ((long)b * nchunk + k) * 2 * C;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += o[c]; q += o[C + c]; }
+    }
+    const double n = (double)HW * cpg, mean = s / n;
+    double var = q / n - mean * mean; if (var < 0) var = 0;
+    stats[((long)b * G + g) * 2] = (float)mean;
+    stats[((long)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+template <typename T>
+__global__ void gn_apply_kernel(const void* x_, const float* stats, const void* gamma_, const void* beta_, void* y_, int B, int HW, int C, int G, int swish) {
+    const long total = (long)B * HW * C;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int cpg = C / G;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C); const long b = i / ((long)HW * C);
+        const float* stt = stats + (b * G + c / cpg) * 2;
+        float v = (ET<T>::ld((const T*)x_ + i) - stt[0]) * stt[1] * ET<T>::ld((const T*)gamma_ + c) + ET<T>::ld((const T*)beta_ + c);
+        v = ET<T>::rnd(v);
+        if (swish) v = v / (1.0f + expf(-v));
+        ET<T>::st((T*)y_ + i, v);
+    }
+}
+extern "C" void car_launch_groupnorm(int mode, const void* x, const void* gamma, const void* beta, void* y, float* part, float* stats,
+                                     int B, int HW, int C, int G, float eps, int swish, hipStream_t st) {
+    const int nchunk = (HW + GN_CHUNK - 1) / GN_CHUNK;
+    const size_t shb = (2 * C + 512) * sizeof(float);
+    if (mode == 1) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
+    else hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, st, part, stats, nchunk, C, G, HW, eps);
+    long total = (long)B * HW * C; int g = (int)((total + 255) / 256); if (g > 8192) g = 8192;
+    LAUNCH_T(mode, gn_apply_kernel, dim3(g), dim3(256), st, x, stats, gamma, beta, y, B, HW, C, G, swish);
+}
+
+// ------------------------------------------------------------------ codebook lookup + post_quant_conv (vq_model.py:262-277, :49)
+// z[b,p,:] = Wpq[zc, cd] @ (cb[tok] / max(||cb[tok]||, 1e-12)) + bias     -> NHWC [B, hw, zc]
+template <typename T>
+__global__ void vq_lookup_kernel(const int* tok, const float* cb, const float* wpq, const float* bpq, void* z_, long npix, int cd, int zc, int ncode) {
+    const long total = npix * zc;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % zc); const long pix = i / zc;
+        int t = tok[pix]; t = t < 0 ? 0 : (t >= ncode ? ncode - 1 : t);
+        const float* e = cb + (long)t * cd;
+        float nn = 0.f;
+        for (int k = 0; k < cd; ++k) nn += e[k] * e[k];
+        const float inv = 1.0f / fmaxf(sqrtf(nn), 1e-12f);
+        float acc = 0.f;
+        for (int k = 0; k < cd; ++k) acc = fmaf(wpq[c * cd + k], e[k] * inv, acc);
+        ET<T>::st((T*)z_ + i, acc + bpq[c]);
+    }
+}
+extern "C" void car_launch_vq_lookup(int mode, const int* tok, const float* cb, const float* wpq, const float* bpq, void* z, long npix, int cd, int zc, int ncode, hipStream_t st) {
+    long total = npix * zc; int g = (int)((total + 255) / 256); if (g > 4096) g = 4096;
+    LAUNCH_T(mode, vq_lookup_kernel, dim3(g), dim3(256), st, tok, cb, wpq, bpq, z, npix, cd, zc, ncode);
+}
+
+// ------------------------------------------------------------------ conv_out 3x3 C->3 on NHWC input, fp32 NCHW output (vq_model.py:168,194)
+// weights packed [3][9][C]; one lane per output pixel, channels in the inner loop.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_out_kernel(const void* x_, const void* w_, const float* bias, float* out, int B, int H, int W, int C) {
+    const long npix = (long)B * H * W;
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H); const long b = pix / ((long)W * H);
+    const T* X = (const T*)x_; const T* Wt = (const T*)w_;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const T* px = X + ((b * H + yy) * W + xx) * C;
+        const T* w0 = Wt + (0 * 9 + tap) * C; const T* w1 = Wt + (1 * 9 + tap) * C; const T* w2 = Wt + (2 * 9 + tap) * C;
+        for (int c = 0; c < C; ++c) {
+            const float v = ET<T>::ld(px + c);
+            a0 = fmaf(v, ET<T>::ld(w0 + c), a0); a1 = fmaf(v, ET<T>::ld(w1 + c), a1); a2 = fmaf(v, ET<T>::ld(w2 + c), a2);
+        }
+    }
+    const long hw = (long)H * W, o = b * 3 * hw + (long)y * W + x;
+    out[o] = a0 + bias[0]; out[o + hw] = a1 + bias[1]; out[o + 2 * hw] = a2 + bias[2];
+}
+extern "C" void car_launch_conv_out(int mode, const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int C, hipStream_t st) {
+    const long npix = (long)B * H * W;
+    LAUNCH_T(mode, conv_out_kernel, dim3((npix + 255) / 256), dim3(256), st, x, w, bias, out, B, H, W, C);
+}
+
+// ------------------------------------------------------------------ exact-mode SwiGLU on the block-16 interleaved w1|w3 layout
+template <typename T>
+__global__ void swiglu_kernel(const void* in_, void* out_, long rows, int hidden) {
+    const long total = rows * hidden;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % hidden); const long r = i / hidden;
+        const T* row = (const T*)in_ + r * 2 * hidden + (c >> 4) * 32 + (c & 15);
+        const float a = ET<T>::ld(row), g = ET<T>::ld(row + 16);
+        ET<T>::st((T*)out_ + i, ET<T>::rnd(silu_f(a)) * g);
+    }
+}
+extern "C" void car_launch_swiglu(int mode, const void* in, void* out, long rows, int hidden, hipStream_t st) {
+    long total = rows * hidden; int g = (int)((total + 255) / 256); if (g > 4096) g = 4096;
+    LAUNCH_T(mode, swiglu_kernel, dim3(g), dim3(256), st, in, out, rows, hidden);
+}
+
+// ------------------------------------------------------------------ CFG mix + greedy argmax (generate.py:90,105; :59-74 greedy branch)
+// logits fp32 [b, V] (cond rows [0,B), uncond rows [B,2B)).  One block per image.
+//   mixed = use_mix ? u + (c - u) * scale : c;  token = lowest index of the maximum (torch.topk tie rule)
+// writes: out_tokens[i*n_new + step], cur_tok[i] (and cur_tok[B+i] under CFG) = forced ? forced[i*n_new+step] : token,
+// optional logits_out[(i*n_new + step)*V + :] = mixed.
+struct SampleP {
+    const float* logits; int B, V, use_cfg; float cfg_scale; int cfg_interval;
+    const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
+};
+__global__ __launch_bounds__(256) void sample_greedy_kernel(SampleP p) {
+    __shared__ float smv[4]; __shared__ int smi[4];
+    const int i = blockIdx.x, step = *p.step_ptr;
+    const float* c = p.logits + (long)i * p.V;
+    const float* u = p.use_cfg ? p.logits + (long)(i + p.B) * p.V : nullptr;
+    // cfg_flag of decode_n_tokens: loop index = step-1; flag drops once (step-1) > cfg_interval
+    const bool mix = p.use_cfg && !(p.cfg_interval > -1 && (step - 1) > p.cfg_interval);
+    float best = -INFINITY; int bi = 0x7fffffff;
+    float* lo = p.logits_out ? p.logits_out + ((long)i * p.n_new + step) * p.V : nullptr;
+    for (int j = threadIdx.x; j < p.V; j += blockDim.x) {
+        float v = c[j];
+        if (mix) v = u[j] + (c[j] - u[j]) * p.cfg_scale;
+        if (lo) lo[j] = v;
+        if (v > best) { best = v; bi = j; }   // strided ascending j per thread: first max kept
+    }
+    // wave reduce (max value, then min index)
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smv[w] = best; smi[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) if (smv[k] > best || (smv[k] == best && smi[k] < bi)) { best = smv[k]; bi = smi[k]; }
+        p.out_tokens[(long)i * p.n_new + step] = bi;
+        const int fb = p.forced ? p.forced[(long)i * p.n_new + step] : bi;
+        p.cur_tok[i] = fb;
+        if (p.use_cfg) p.cur_tok[i + p.B] = fb;
+    }
+}
+extern "C" void car_launch_sample_greedy(const SampleP* p, hipStream_t st) {
+    hipLaunchKernelGGL(sample_greedy_kernel, dim3(p->B), dim3(256), 0, st, *p);
+}
+
+// step bookkeeping: pos += 1, step += 1 (device-side so a captured hipGraph can be replayed)
+__global__ void advance_kernel(int* pos, int* step) { if (threadIdx.x == 0) { *pos += 1; *step += 1; } }
+extern "C" void car_launch_advance(int* pos, int* step, hipStream_t st) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, pos, step); }
+
+// ------------------------------------------------------------------ V^T builder for the GEMM-form attention
+// src [B, Tn, ld] (column offset already applied), C channels -> dst [B, C, Tpad], zero padded in t.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const void* src_, long ld, long sb, void* dst_, int Tn, int Tpad, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const T* src = (const T*)src_ + (long)b * sb; T* dst = (T*)dst_ + (long)b * C * Tpad;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, c = c0 + tx;
+        tile[r][tx] = (t < Tn && c < C) ? ET<T>::ld(src + (long)t * ld + c) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        if (c < C && t < Tpad) ET<T>::st(dst + (long)c * Tpad + t, tile[tx][r]);
+    }
+}
+extern "C" void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st) {
+    dim3 g((Tpad + 31) / 32, (C + 31) / 32, B);
+    LAUNCH_T(mode, transpose_pad_kernel, g, dim3(256), st, src, ld, sb, dst, Tn, Tpad, C);
+}

@@ -1,0 +1,164 @@
+"""Thin host-side wrapper over the C ABI: owns one car_ctx, feeds it reference-named weights,
+hands it data_ptr()s of PyTorch-ROCm tensors on the current stream.  PyTorch here is plumbing
+(device memory + streams); all arithmetic of the path runs in libcontrolar_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from .config import PathConfig
+
+
+def _stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.CAR_DT_F32
+    if t.dtype == torch.bfloat16:
+        return L.CAR_DT_BF16
+    raise TypeError(f"unsupported tensor dtype {t.dtype} (float32 or bfloat16)")
+
+
+class Engine:
+    """One context = one set of weights in one arithmetic mode ('fp32' exact | 'bf16' fast)."""
+
+    def __init__(self, cfg: PathConfig, precision: str = "bf16", device: Optional[torch.device] = None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("controlar_amd needs a HIP device (no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        self.cfg = cfg
+        self.precision = precision
+        self.mode = {"fp32": L.CAR_F32, "none": L.CAR_F32, "bf16": L.CAR_BF16}[precision]
+        self.dtype = torch.float32 if self.mode == L.CAR_F32 else torch.bfloat16
+        g, v, q = cfg.gpt, cfg.vit, cfg.vq
+        cc = L.CarConfig()
+        cc.abi_version, cc.mode = L.CAR_ABI_VERSION, self.mode
+        cc.dim, cc.n_layer, cc.n_head, cc.ffn_hidden, cc.vocab_size = g.dim, g.n_layer, g.n_head, g.ffn_hidden, g.vocab_size
+        cc.cls_token_num, cc.block_size, cc.caption_dim = g.cls_token_num, g.block_size, g.caption_dim
+        cc.norm_eps, cc.rope_base = g.norm_eps, g.rope_base
+        cc.vit_hidden, cc.vit_layers, cc.vit_heads, cc.vit_mlp = v.hidden, v.layers, v.heads, v.mlp
+        cc.vit_patch, cc.vit_pos_grid, cc.vit_ln_eps = v.patch, v.pos_grid, v.ln_eps
+        # dinov2_adapter.py:19-23: nearest for canny/seg, bicubic(align_corners=True) otherwise
+        cc.resize_mode = L.CAR_RESIZE_NEAREST if g.condition_type in ("canny", "seg") else L.CAR_RESIZE_BICUBIC_AC
+        cc.codebook_size, cc.codebook_dim, cc.z_channels, cc.vq_ch = q.codebook_size, q.codebook_embed_dim, q.z_channels, q.ch
+        cc.vq_num_res_blocks, cc.vq_n_mult, cc.gn_eps = q.num_res_blocks, len(q.ch_mult), q.gn_eps
+        for i, m in enumerate(q.ch_mult):
+            cc.vq_ch_mult[i] = m
+        self._cc = cc
+        h = C.c_void_p()
+        rc = self.lib.car_create(C.byref(h), C.byref(cc))
+        if rc != 0:
+            raise RuntimeError("car_create: " + self.lib.car_last_error(None).decode())
+        self._h = h
+
+    # ------------------------------------------------------------------ errors / lifecycle
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.car_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.car_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], finalize: bool = False):
+        """Accepts the reference's state_dict names (gpt_t2i.Transformer incl. adapter.model.*, VQModel)."""
+        for name, t in sd.items():
+            if not torch.is_floating_point(t):
+                continue
+            t = t.detach()
+            if t.dtype not in (torch.float32, torch.bfloat16):
+                t = t.float()
+            t = t.contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            self._check(self.lib.car_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(), _dt(t)),
+                        f"car_load_tensor({name})")
+        if finalize:
+            self.finalize()
+
+    def finalize(self):
+        self._check(self.lib.car_finalize_weights(self._h), "car_finalize_weights")
+
+    # ------------------------------------------------------------------ path stages
+    def encode_control(self, img: torch.Tensor, want_output: bool = False) -> Optional[torch.Tensor]:
+        """model.adapter_mlp(model.adapter(img))  (generate.py:136-138).  img [B,3,H,W] in [-1,1]."""
+        assert img.dim() == 4 and img.shape[1] == 3
+        img = img.to(self.device)
+        if img.dtype not in (torch.float32, torch.bfloat16):
+            img = img.float()
+        img = img.contiguous()
+        B, _, H, W = img.shape
+        out = None
+        if want_output:
+            out = torch.empty(B, (H // 16) * (W // 16), self.cfg.gpt.dim, dtype=self.dtype, device=self.device)
+        self._check(self.lib.car_encode_control(self._h, C.c_void_p(img.data_ptr()), _dt(img), B, H, W,
+                                                C.c_void_p(out.data_ptr() if out is not None else 0), C.c_void_p(_stream_ptr())),
+                    "car_encode_control")
+        return out
+
+    def generate(self, cond: torch.Tensor, max_new_tokens: int, emb_masks: Optional[torch.Tensor] = None,
+                 cfg_scale: float = 1.0, cfg_interval: int = -1, use_control: bool = True, control_strength: float = 1.0,
+                 temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, sample_logits: bool = False, seed: int = 0,
+                 forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
+        cond = cond.to(self.device)
+        if cond.dtype not in (torch.float32, torch.bfloat16):
+            cond = cond.float()
+        cond = cond.contiguous()
+        B, T, cap = cond.shape
+        assert T == self.cfg.gpt.cls_token_num and cap == self.cfg.gpt.caption_dim
+        mask_t = None
+        if emb_masks is not None:
+            assert emb_masks.shape[0] == B and emb_masks.shape[-1] == T          # generate.py:185-186
+            mask_t = emb_masks.to(device=self.device, dtype=torch.int64).contiguous()
+        sp = L.CarSampling()
+        sp.cfg_scale, sp.cfg_interval, sp.temperature, sp.top_k = float(cfg_scale), int(cfg_interval), float(temperature), int(top_k or 0)
+        sp.top_p, sp.sample_logits, sp.seed, sp.control_strength = float(top_p), int(bool(sample_logits)), int(seed), float(control_strength)
+        out = torch.empty(B, max_new_tokens, dtype=torch.int32, device=self.device)
+        forced = None
+        if forced_tokens is not None:
+            forced = forced_tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        logits = torch.empty(B, max_new_tokens, self.cfg.gpt.vocab_size, dtype=torch.float32, device=self.device) if return_logits else None
+        self._check(self.lib.car_generate(self._h, C.c_void_p(cond.data_ptr()), _dt(cond),
+                                          C.c_void_p(mask_t.data_ptr() if mask_t is not None else 0), B, int(max_new_tokens),
+                                          int(bool(use_control)), C.byref(sp), C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(forced.data_ptr() if forced is not None else 0),
+                                          C.c_void_p(logits.data_ptr() if logits is not None else 0), C.c_void_p(_stream_ptr())),
+                    "car_generate")
+        return (out, logits) if return_logits else out
+
+    def vq_decode(self, tokens: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        """VQModel.decode_code(tokens, [B,C,h,w]) -> fp32 [B,3,16h,16w]  (vq_model.py:53-56)."""
+        tokens = tokens.to(device=self.device, dtype=torch.int32).contiguous().view(-1, h * w)
+        B = tokens.shape[0]
+        up = 2 ** (len(self.cfg.vq.ch_mult) - 1)
+        out = torch.empty(B, 3, h * up, w * up, dtype=torch.float32, device=self.device)
+        self._check(self.lib.car_vq_decode(self._h, C.c_void_p(tokens.data_ptr()), B, h, w, C.c_void_p(out.data_ptr()),
+                                           C.c_void_p(_stream_ptr())), "car_vq_decode")
+        return out
+
+    def stats(self) -> dict:
+        s = L.CarStats()
+        self._check(self.lib.car_get_stats(self._h, C.byref(s)), "car_get_stats")
+        return dict(decode_ms=s.decode_ms, prefill_ms=s.prefill_ms, decode_steps=s.decode_steps,
+                    decode_algo_bytes=s.decode_algo_bytes, decode_kernels_per_step=s.decode_kernels_per_step,
+                    graph_used=bool(s.graph_used))
+
+    def control_tokens(self, k: int, b: int, n_tok: int) -> torch.Tensor:
+        n = b * n_tok * self.cfg.gpt.dim
+        buf = torch.empty(n, dtype=torch.float32)
+        self._check(self.lib.car_debug_control_tokens(self._h, k, C.c_void_p(buf.data_ptr()), n), "car_debug_control_tokens")
+        return buf.view(b, n_tok, self.cfg.gpt.dim)

@@ -1,0 +1,145 @@
+/*
+ * controlar_hip.h — C ABI of libcontrolar_hip.so: the MI355X (gfx950) implementation of
+ * ControlAR's conditional-decoding hot path
+ *     DINOv2 control encoder -> LlamaGen AR decode with per-token control fusion -> VQGAN decoder.
+ *
+ * The reference (hustvl/ControlAR) has no FFI/plugin layer: its seams are Python callables
+ * (SURVEY.md §8b).  Each entry point below replaces one of those callables; the ctypes binding
+ * that a reference maintainer would add is shown in INTEGRATION.md and shipped in
+ * controlar_amd/_lib.py.  No torch types cross this boundary: plain pointers, sizes, ints.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; car_last_error(ctx) gives the text
+ *     (reference raises Python exceptions / asserts: generate.py:173,185-186; gpt_t2i.py:229).
+ *   - all data pointers are DEVICE pointers unless stated; the caller (PyTorch) owns inputs and
+ *     outputs; the library owns packed weights, KV caches, control-token buffers, hipGraphs and
+ *     workspaces (SURVEY.md §8b "Ownership").
+ *   - work is enqueued on the hipStream_t passed as `stream` (void* so the header needs no HIP
+ *     include); functions that return values to the HOST say so and synchronise that stream.
+ *   - a context is re-entrant per ctx but not thread-safe within one ctx.
+ */
+#ifndef CONTROLAR_HIP_H
+#define CONTROLAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAR_ABI_VERSION 1
+
+/* arithmetic mode of a context */
+enum { CAR_F32 = 0,   /* "exact" mode: fp32 weights/activations/FMA — parity contract vs the fp32 CPU reference */
+       CAR_BF16 = 1   /* fast mode: bf16 storage, fp32 accumulate, the reference's bf16 rounding points */ };
+
+/* element types accepted by car_load_tensor / image inputs */
+enum { CAR_DT_F32 = 0, CAR_DT_BF16 = 1, CAR_DT_I32 = 2, CAR_DT_I64 = 3, CAR_DT_U8 = 4 };
+
+/* resize in front of the encoder — reference: autoregressive/models/dinov2_adapter.py:16-24 */
+enum { CAR_RESIZE_NEAREST = 0,          /* condition_type in {'canny','seg'} */
+       CAR_RESIZE_BICUBIC_AC = 1 };     /* everything else: bicubic, align_corners=True */
+
+typedef struct car_config {
+    int32_t abi_version;      /* = CAR_ABI_VERSION */
+    int32_t mode;             /* CAR_F32 | CAR_BF16 */
+    /* LlamaGen transformer — reference: autoregressive/models/gpt_t2i.py:31-60 ModelArgs */
+    int32_t dim, n_layer, n_head, ffn_hidden, vocab_size;
+    int32_t cls_token_num;    /* text prefix length T (120) */
+    int32_t block_size;       /* rope grid = sqrt(block_size)  (gpt_t2i.py:351-353) */
+    int32_t caption_dim;      /* 2048 */
+    float   norm_eps;         /* 1e-5 */
+    float   rope_base;        /* 10000 */
+    /* control encoder — HF Dinov2Config as built by dinov2_adapter.py:13 */
+    int32_t vit_hidden, vit_layers, vit_heads, vit_mlp, vit_patch, vit_pos_grid;
+    float   vit_ln_eps;       /* 1e-6 */
+    int32_t resize_mode;      /* CAR_RESIZE_* */
+    /* VQGAN decoder — reference: tokenizer/tokenizer_image/vq_model.py:12-24,129-169 */
+    int32_t codebook_size, codebook_dim, z_channels, vq_ch, vq_num_res_blocks;
+    int32_t vq_n_mult;        /* number of entries used in vq_ch_mult (5 for VQ-16) */
+    int32_t vq_ch_mult[8];
+    float   gn_eps;           /* 1e-6 */
+    int32_t reserved[8];
+} car_config;
+
+/* sampling parameters — reference: generate.py:59-74 sample(), :134 generate() kwargs */
+typedef struct car_sampling {
+    float    cfg_scale;        /* > 1 doubles the batch (cond | uncond)           generate.py:156-164 */
+    int32_t  cfg_interval;     /* -1 = always mix                                  generate.py:121-122 */
+    float    temperature;      /* logits / max(T,1e-5)                             generate.py:60 */
+    int32_t  top_k;            /* 0 = off                                          generate.py:33-38 */
+    float    top_p;            /* 1 = off                                          generate.py:40-55 */
+    int32_t  sample_logits;    /* 0 = greedy topk(probs,1): ties -> lowest index   generate.py:71-73 */
+    uint64_t seed;             /* counter-based RNG seed when sample_logits != 0 */
+    float    control_strength; /* ignored (=1) when cfg_scale <= 1                 generate.py:87-92 */
+    int32_t  reserved[4];
+} car_sampling;
+
+typedef struct car_ctx car_ctx;
+
+/* lifecycle */
+int  car_create(car_ctx** out, const car_config* cfg);
+void car_destroy(car_ctx* ctx);
+const char* car_last_error(const car_ctx* ctx);   /* also valid with ctx == NULL after a failed car_create */
+int  car_abi_version(void);
+
+/*
+ * Weight loading — keyed by the reference state_dict names (SURVEY.md §8b "Weight contract"):
+ * gpt_t2i.Transformer names (incl. HF Dinov2 under "adapter.model.") and VQModel names.
+ * `ptr` may be a host or device pointer; dtype CAR_DT_F32 or CAR_DT_BF16; shape row-major.
+ * Unknown names return 0 and are ignored when they are reference tensors unused at inference
+ * (condition_embeddings.weight, *.mask_token, encoder.*, quant_conv.*), non-zero otherwise.
+ * car_finalize_weights checks that every tensor the path needs has arrived and packs them.
+ */
+int car_load_tensor(car_ctx* ctx, const char* name, const void* ptr, const int64_t* shape, int32_t ndim, int32_t dtype);
+int car_finalize_weights(car_ctx* ctx);
+
+/*
+ * Control encoder + adapter MLP — replaces model.adapter(condition) + model.adapter_mlp(...)
+ * (generate.py:136-138; dinov2_adapter.py:26-29).  img: [B,3,H,W] in [-1,1], dtype F32/BF16.
+ * out (optional, may be NULL): [B,(H/16)(W/16),dim] in the context's element type; the result is
+ * always kept inside the context for the next car_generate call.
+ */
+int car_encode_control(car_ctx* ctx, const void* img, int32_t img_dtype, int32_t B, int32_t H, int32_t W,
+                       void* out, void* stream);
+
+/*
+ * generate() — replaces autoregressive/models/generate.py:134-204 (t2i branch).
+ *   text_emb  [B,T,caption_dim] (F32/BF16 per text_dtype), emb_mask [B,T] int64 (may be NULL),
+ *   n_new     = max_new_tokens, grid_w = token-grid width of the image (W/16), used only for shape
+ *               checks (RoPE is indexed linearly as the reference does, gpt_t2i.py:454),
+ *   use_control != 0 consumes the control tokens of the preceding car_encode_control (same B),
+ *   out_tokens [B,n_new] int32 (device).
+ * Debug/teacher-forcing extras (tests): forced_tokens [B,n_new] int32 or NULL
+ * (token fed back at step i is forced[i]); logits_out [B,n_new,vocab] fp32 or NULL (post-CFG logits
+ * handed to sample()).
+ */
+int car_generate(car_ctx* ctx, const void* text_emb, int32_t text_dtype, const int64_t* emb_mask,
+                 int32_t B, int32_t n_new, int32_t use_control, const car_sampling* sp,
+                 int32_t* out_tokens, const int32_t* forced_tokens, float* logits_out, void* stream);
+
+/*
+ * VQModel.decode_code(code_b, [B,C,h,w], channel_first=True) — tokenizer/tokenizer_image/vq_model.py:53-56.
+ * tokens [B,h*w] int32 -> out fp32 NCHW [B,3,16h,16w].
+ */
+int car_vq_decode(car_ctx* ctx, const int32_t* tokens, int32_t B, int32_t h, int32_t w, float* out_nchw, void* stream);
+
+/* Introspection used by tests and bench.py */
+typedef struct car_stats {
+    double  decode_ms;          /* HIP-event time of the last car_generate's decode loop (n_new-1 steps) */
+    double  prefill_ms;         /* prefill + control-token MLPs */
+    int64_t decode_steps;
+    int64_t decode_algo_bytes;  /* algorithmic HBM bytes of that loop (weights once/step + valid KV), DESIGN.md §4 */
+    int32_t decode_kernels_per_step;
+    int32_t graph_used;
+    int32_t reserved[6];
+} car_stats;
+int car_get_stats(car_ctx* ctx, car_stats* out);
+
+/* Copies the cached control tokens of layer-group k (0..2) [b,n_tok,dim] as fp32 to a HOST buffer (tests). */
+int car_debug_control_tokens(car_ctx* ctx, int32_t k, float* host_out, int64_t max_elems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTROLAR_HIP_H */
