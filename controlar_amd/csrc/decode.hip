@@ -19,8 +19,10 @@ struct AttnP {
     void* out;              // [b, dim] T                        (nsplit == 1)
     float* part;            // [b, H, nsplit, 66] fp32 (m, l, o[64]) (nsplit > 1)
     int H, S_max, T, dim, nsplit;
+    const float* qkv_parts; int qkv_ks; long qkv_stride;   // fast path: wqkv output as fp32 split-K partials [ks][b][3*dim]
 };
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <typename T> struct VecT;
 template <> struct VecT<bf16_t> { static constexpr int EPL = 8; };   // elements per 16-byte lane load
 template <> struct VecT<float>  { static constexpr int EPL = 4; };
@@ -54,14 +56,20 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(AttnP p) {
     T* vc = (T*)p.vcache + ((long)b * p.H + h) * p.S_max * 64;
 
     // ---- RoPE on q and k (fp32 rotate, round to T), v passthrough; new k/v go to the cache
+    auto ldqkv = [&](int col) -> float {
+        if (!p.qkv_parts) return ET<T>::ld(qkv + col);
+        float a = 0.f;
+        for (int s = 0; s < p.qkv_ks; ++s) a += p.qkv_parts[s * p.qkv_stride + (long)b * 3 * p.dim + col];
+        return ET<T>::rnd(a);         // the wqkv Linear output is rounded to T
+    };
     if (tid < 32) {
         const float cs = p.rope[((long)pos * 32 + tid) * 2], sn = p.rope[((long)pos * 32 + tid) * 2 + 1];
-        const float q0 = ET<T>::ld(qkv + h * 64 + 2 * tid), q1 = ET<T>::ld(qkv + h * 64 + 2 * tid + 1);
-        const float k0 = ET<T>::ld(qkv + p.dim + h * 64 + 2 * tid), k1 = ET<T>::ld(qkv + p.dim + h * 64 + 2 * tid + 1);
+        const float q0 = ldqkv(h * 64 + 2 * tid), q1 = ldqkv(h * 64 + 2 * tid + 1);
+        const float k0 = ldqkv(p.dim + h * 64 + 2 * tid), k1 = ldqkv(p.dim + h * 64 + 2 * tid + 1);
         sq[2 * tid] = ET<T>::rnd(q0 * cs - q1 * sn); sq[2 * tid + 1] = ET<T>::rnd(q1 * cs + q0 * sn);
         sk[2 * tid] = ET<T>::rnd(k0 * cs - k1 * sn); sk[2 * tid + 1] = ET<T>::rnd(k1 * cs + k0 * sn);
     } else if (tid >= 64 && tid < 128) {
-        sv[tid - 64] = ET<T>::ld(qkv + 2 * p.dim + h * 64 + (tid - 64));
+        sv[tid - 64] = ldqkv(2 * p.dim + h * 64 + (tid - 64));
     }
     __syncthreads();
     if (split == 0 && tid < 64) {
@@ -197,4 +205,120 @@ extern "C" void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* 
     long total = (long)b * Tn * H * 32; int g = (int)((total + 255) / 256); if (g > 4096) g = 4096;
     if (mode == 1) hipLaunchKernelGGL(prefill_rope_kv_kernel<bf16_t>, dim3(g), dim3(256), 0, st, qkv, kc, vc, rope, b, Tn, H, dim, S_max);
     else hipLaunchKernelGGL(prefill_rope_kv_kernel<float>, dim3(g), dim3(256), 0, st, qkv, kc, vc, rope, b, Tn, H, dim, S_max);
+}
+
+// =============================================================================================
+// dec_linear (bf16 fast mode): the weight-streaming skinny GEMM of the decode step.
+//   part[ks][m][n] = sum_{k in slice ks} X[m][k] * W[n][k]        m < b <= 16*NB, fp32 partials
+// Weights are pre-packed at load time into MFMA-fragment order: chunk (rb, kb) = the 16x32 tile
+// W[rb*16 .. +16][kb*32 .. +32] stored as 64 lanes x 16 B (lane l: row l&15, k (l>>4)*8 .. +8),
+// chunks ordered [rb][kb]: a wave streaming one row-block over K reads one contiguous run, 1 KiB per
+// global_load_dwordx4 wave-instruction (fully coalesced, non-temporal: each byte is used once per step).
+// v_mfma_f32_16x16x32_bf16 with A = weight chunk, B = X^T fragment from LDS; D[n][m].
+// A workgroup = 4 waves = 4 adjacent row-blocks sharing one LDS copy of the X slice; split-K across
+// workgroups (blockIdx.y); the KS partial slices are summed by the CONSUMER kernel's loads
+// (rmsnorm / dec_attn / next dec_linear / sampler), so no reduction kernel and no atomics:
+// deterministic, fixed summation order.
+struct LinP {
+    const bf16_t* W; const void* X; float* part;
+    int xmode;      // 0: X is bf16 [b][K];  1: X[m][k] = swiglu of fp32 partials [xks][b][2K] in the block-16 interleaved w1|w3 layout
+    int xks;
+    int b, N, K, KS;
+};
+
+template <int NB>
+__global__ __launch_bounds__(256) void dec_linear_kernel(LinP p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t xs[];     // [16*NB][KC + 8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KC = p.K / p.KS, nkb = KC / 32, ld = KC + 8;
+    const int ks = blockIdx.y, k0 = ks * KC;
+    const int rb = blockIdx.x * 4 + wave;
+    const bool active = rb * 16 < p.N;
+    const u32x4* wp = (const u32x4*)p.W + ((long)rb * (p.K / 32) + (k0 / 32)) * 64 + lane;
+
+    // first weight batch goes out before X staging so HBM latency overlaps it
+    u32x4 wa[8], wb[8];
+    const u32x4 zw = (u32x4){0u, 0u, 0u, 0u};
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { wa[i] = zw; if (active && i < nkb) wa[i] = __builtin_nontemporal_load(wp + (long)i * 64); }
+
+    // ---- stage X[0:16*NB][k0:k0+KC] into LDS (rows >= b are zero)
+    const int rows = 16 * NB, cpr = KC / 8;            // 16-byte chunks per row
+    for (int c = tid; c < rows * cpr; c += 256) {
+        const int m = c / cpr, kc = (c - m * cpr) * 8;
+        uint4 v = z4;
+        if (m < p.b) {
+            if (p.xmode == 0) v = *(const uint4*)((const bf16_t*)p.X + (long)m * p.K + k0 + kc);
+            else {
+                // hidden index k -> a at column (k/16)*32 + k%16, c at +16 of the interleaved [2K] row; 8 consecutive k stay inside one block of 16
+                const int k = k0 + kc, col = (k >> 4) * 32 + (k & 15);
+                float a[8], g[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a[e] = 0.f; g[e] = 0.f; }
+                for (int s = 0; s < p.xks; ++s) {
+                    const float* src = (const float*)p.X + ((long)s * p.b + m) * (2L * p.K) + col;
+                    const float4 a0 = *(const float4*)src, a1 = *(const float4*)(src + 4), g0 = *(const float4*)(src + 16), g1 = *(const float4*)(src + 20);
+                    a[0] += a0.x; a[1] += a0.y; a[2] += a0.z; a[3] += a0.w; a[4] += a1.x; a[5] += a1.y; a[6] += a1.z; a[7] += a1.w;
+                    g[0] += g0.x; g[1] += g0.y; g[2] += g0.z; g[3] += g0.w; g[4] += g1.x; g[5] += g1.y; g[6] += g1.z; g[7] += g1.w;
+                }
+                unsigned o[4];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    // reference rounding points (gpt_t2i.py:217): w1 out ->bf16, silu ->bf16, w3 out ->bf16, product ->bf16
+                    const float s0 = bf2f(f2bf(silu_f(bf2f(f2bf(a[e]))))) * bf2f(f2bf(g[e]));
+                    const float s1 = bf2f(f2bf(silu_f(bf2f(f2bf(a[e + 1]))))) * bf2f(f2bf(g[e + 1]));
+                    o[e >> 1] = (unsigned)f2bf(s0) | ((unsigned)f2bf(s1) << 16);
+                }
+                v = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        *(uint4*)(xs + m * ld + kc) = v;
+    }
+    __syncthreads();
+    if (!active) return;
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xl = xs + (lane & 15) * ld + (lane >> 4) * 8;
+
+    auto compute = [&](const u32x4 (&w)[8], int kb0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (kb0 + i < nkb) {
+                const bf16x8 a = *(const bf16x8*)&w[i];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const bf16x8 x = *(const bf16x8*)(xl + n * 16 * ld + (kb0 + i) * 32);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, x, acc[n], 0, 0, 0);
+                }
+            }
+        }
+    };
+    for (int kb0 = 0; kb0 < nkb; kb0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wb[i] = zw; if (kb0 + 8 + i < nkb) wb[i] = __builtin_nontemporal_load(wp + (long)(kb0 + 8 + i) * 64); }
+        compute(wa, kb0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wa[i] = zw; if (kb0 + 16 + i < nkb) wa[i] = __builtin_nontemporal_load(wp + (long)(kb0 + 16 + i) * 64); }
+        compute(wb, kb0 + 8);
+    }
+    // D[row=(lane>>4)*4+r][col=lane&15]: n = rb*16 + (lane>>4)*4 + r, m = nb*16 + (lane&15) -> 16-byte fp32 store per lane
+    const int n0 = rb * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int m = n * 16 + (lane & 15);
+        if (m < p.b) *(f32x4*)(p.part + ((long)ks * p.b + m) * p.N + n0) = acc[n];
+    }
+}
+
+extern "C" void car_launch_dec_linear(const LinP* p, hipStream_t st) {
+    const int KC = p->K / p->KS;
+    const int NB = (p->b + 15) / 16;
+    dim3 g((p->N + 63) / 64, p->KS);
+    if (NB <= 1) hipLaunchKernelGGL(dec_linear_kernel<1>, g, dim3(256), (size_t)16 * (KC + 8) * 2, st, *p);
+    else if (NB == 2) hipLaunchKernelGGL(dec_linear_kernel<2>, g, dim3(256), (size_t)32 * (KC + 8) * 2, st, *p);
+    else if (NB <= 4) hipLaunchKernelGGL(dec_linear_kernel<4>, g, dim3(256), (size_t)64 * (KC + 8) * 2, st, *p);
+    else hipLaunchKernelGGL(dec_linear_kernel<8>, g, dim3(256), (size_t)128 * (KC + 8) * 2, st, *p);
 }

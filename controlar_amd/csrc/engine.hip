@@ -21,14 +21,22 @@ struct NormP {
     const void* h_in; const void* emb; const int* idx; void* h_out; void* xn; const void* w;
     const void* ctrl; const int* pos; int add_mode; int T; int n_tok; float cs;
     int D; float eps;
+    const float* parts; int parts_ks; long parts_stride;
 };
 struct SampleP {
     const float* logits; int B, V, use_cfg; float cfg_scale; int cfg_interval;
     const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
+    int logits_ks; long logits_stride; int round_bf16;
 };
 struct AttnP {
     const void* qkv; void* kcache; void* vcache; const float* rope; const int* pos; const unsigned char* emb_mask;
     void* out; float* part; int H, S_max, T, dim, nsplit;
+    const float* qkv_parts; int qkv_ks; long qkv_stride;
+};
+struct LinP {
+    const bf16_t* W; const void* X; float* part;
+    int xmode; int xks;
+    int b, N, K, KS;
 };
 extern "C" {
 void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
@@ -50,6 +58,8 @@ void car_launch_sample_greedy(const SampleP* p, hipStream_t st);
 void car_launch_advance(int* pos, int* step, hipStream_t st);
 void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st);
 void car_launch_dec_attn(int mode, const AttnP* p, int b, hipStream_t st);
+void car_launch_dec_linear(const LinP* p, hipStream_t st);
+void car_launch_swiglu_parts(const float* parts, int ks, long stride, void* out, int rows, int hidden, hipStream_t st);
 void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, hipStream_t st);
 }
 
@@ -88,6 +98,7 @@ struct car_ctx {
     DevBuf ctrl[3];      // cached control tokens [b, n_tok, dim]
     DevBuf kv;           // [n_layer][2][b, H, S_max, 64]
     DevBuf ws[12];       // scratch
+    DevBuf dec_parts;    // split-K partials of the decode linears (fp32)
     DevBuf scal;         // device ints: pos, step, cur_tok[b]
     DevBuf tok_out;      // [B, n_new] int32
     DevBuf maskb;        // [b, T] uint8
@@ -167,7 +178,7 @@ extern "C" void car_destroy(car_ctx* c) {
     for (auto& kv : c->resize_cache) { (void)hipFree(kv.second.iy); (void)hipFree(kv.second.ix); if (kv.second.wy) (void)hipFree(kv.second.wy); if (kv.second.wx) (void)hipFree(kv.second.wx); }
     if (c->rope) (void)hipFree(c->rope);
     c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
-    c->scal.release(); c->tok_out.release(); c->maskb.release();
+    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -192,6 +203,26 @@ static int upload(car_ctx* c, const std::string& name, const std::vector<float>&
     auto it = c->w.find(name);
     if (it != c->w.end() && it->second.p) (void)hipFree(it->second.p);
     c->w[name] = t;
+    return 0;
+}
+
+// dec_linear weight image: [N/16][K/32] chunks of 64 lanes x 8 bf16 (lane l: row l&15, k (l>>4)*8..+8) — decode.hip
+static int upload_packed(car_ctx* c, const std::string& name, const std::vector<float>& h, int N, int K) {
+    if (c->mode != CAR_BF16) return 0;
+    if (N % 16 || K % 32) FAIL(c, "%s: decode packing needs N%%16==0 and K%%32==0 (got %d x %d)", name.c_str(), N, K);
+    std::vector<bf16_t> pk((size_t)N * K);
+    const int nkb = K / 32;
+    for (int rb = 0; rb < N / 16; ++rb) for (int kb = 0; kb < nkb; ++kb) for (int l = 0; l < 64; ++l) {
+        const float* src = &h[(size_t)(rb * 16 + (l & 15)) * K + kb * 32 + (l >> 4) * 8];
+        bf16_t* dst = &pk[(((size_t)rb * nkb + kb) * 64 + l) * 8];
+        for (int e = 0; e < 8; ++e) dst[e] = f2bf(src[e]);
+    }
+    Wt t; t.shape = {N, K}; t.numel = (int64_t)N * K;
+    HIPCHK(c, hipMalloc(&t.p, pk.size() * 2));
+    HIPCHK(c, hipMemcpy(t.p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    auto it = c->w.find(name + "#pk");
+    if (it != c->w.end() && it->second.p) (void)hipFree(it->second.p);
+    c->w[name + "#pk"] = t;
     return 0;
 }
 
@@ -236,6 +267,7 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
             memcpy(&pk[(blk + 16) * g.dim], &w3[(size_t)r * g.dim], (size_t)g.dim * 4);
         }
         int rc = upload(c, base + "w13.weight", pk, {2 * (int64_t)g.ffn_hidden, g.dim});
+        if (!rc) rc = upload_packed(c, base + "w13.weight", pk, 2 * g.ffn_hidden, g.dim);
         c->host_keep.erase(other);
         return rc;
     }
@@ -267,6 +299,10 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
         return upload(c, name, pk, {Co, 9 * (int64_t)Ci});
     }
     if (starts_with(name, "decoder.") && ndim == 4) return upload(c, name, h, {shp[0], shp[1]});   // 1x1 conv
+    if (ndim == 2 && (ends_with(name, "attention.wqkv.weight") || ends_with(name, "attention.wo.weight") ||
+                      ends_with(name, "feed_forward.w2.weight") || name == "output.weight")) {
+        if (upload_packed(c, name, h, (int)shp[0], (int)shp[1])) return -1;
+    }
     return upload(c, name, h, shp);
 }
 
@@ -535,6 +571,80 @@ extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype
 // ------------------------------------------------------------------------------------- decode step (one token for all b sequences)
 struct StepBufs { void *h, *xn, *qkv, *att, *mid, *mid2; float* part; float* logits; int *pos, *step, *cur; };
 
+// split-K factor of a decode linear: enough workgroups to cover the chip, X slice within 64 KiB of LDS
+static int pick_ks(int N, int K, int b) {
+    const int rg = (N + 63) / 64, nkb = K / 32, NB = b <= 16 ? 1 : (b <= 32 ? 2 : (b <= 64 ? 4 : 8));
+    const int kc_max = 65536 / (32 * NB) - 8;
+    int best = -1;
+    for (int d = 1; d <= nkb; ++d) {
+        if (nkb % d) continue;
+        const int KC = K / d;
+        if (KC > kc_max) continue;
+        if (best < 0) best = d;
+        if (KC < 128) break;
+        best = d;
+        if (rg * d >= 200) break;
+    }
+    return best < 0 ? nkb : best;
+}
+
+struct FastBufs { float *pq, *po, *p13, *p2, *pl; int ksq, kso, ks13, ks2, ksl; };
+
+// bf16 fast path: 7 kernels per layer, every linear is a dec_linear whose split-K partials are summed by its consumer
+static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const FastBufs& fb, int b, int S_max, int n_tok, int nsplit, bool use_ctrl,
+                                    float cs, const SampleP& sp_tmpl, hipStream_t st) {
+    const car_config& g = c->cfg; const size_t e = c->esz;
+    const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, li = g.n_layer / 3, V = g.vocab_size;
+    const size_t kv_layer = (size_t)b * Hn * S_max * 64;
+    int nk = 0;
+    auto lin = [&](const std::string& wname, const void* X, int xmode, int xks, float* part, int N, int K, int KS) {
+        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + "#pk"); lp.X = X; lp.part = part; lp.xmode = xmode; lp.xks = xks; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS;
+        car_launch_dec_linear(&lp, st); ++nk;
+    };
+    for (int l = 0; l < g.n_layer; ++l) {
+        const std::string L = "layers." + std::to_string(l) + ".";
+        {   // [token gather | + previous layer's FFN output] (+ control add) -> h ; attention_norm -> xn
+            NormP np; memset(&np, 0, sizeof(np));
+            np.h_in = sb.h; np.h_out = sb.h; np.xn = sb.xn; np.w = Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            if (l == 0) { np.emb = Wp(c, "tok_embeddings.weight"); np.idx = sb.cur; }
+            else { np.parts = fb.p2; np.parts_ks = fb.ks2; np.parts_stride = (long)b * D; }
+            if (use_ctrl && l % li == 0 && l / li < 3) { np.add_mode = 1; np.ctrl = c->ctrl[l / li].p; np.pos = sb.pos; np.T = g.cls_token_num; np.n_tok = n_tok; np.cs = cs; }
+            car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
+        }
+        lin(L + "attention.wqkv.weight", sb.xn, 0, 0, fb.pq, 3 * D, D, fb.ksq);
+        {
+            AttnP ap; memset(&ap, 0, sizeof(ap));
+            ap.kcache = off(c->kv.p, (size_t)(2 * l) * kv_layer, e); ap.vcache = off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e);
+            ap.rope = c->rope; ap.pos = sb.pos; ap.emb_mask = (const unsigned char*)c->maskb.p; ap.out = sb.att; ap.part = sb.part;
+            ap.H = Hn; ap.S_max = S_max; ap.T = g.cls_token_num; ap.dim = D; ap.nsplit = nsplit;
+            ap.qkv_parts = fb.pq; ap.qkv_ks = fb.ksq; ap.qkv_stride = (long)b * 3 * D;
+            car_launch_dec_attn(CAR_BF16, &ap, b, st); nk += nsplit > 1 ? 2 : 1;
+        }
+        lin(L + "attention.wo.weight", sb.att, 0, 0, fb.po, D, D, fb.kso);
+        {   // h += attention output ; ffn_norm -> xn
+            NormP np; memset(&np, 0, sizeof(np));
+            np.h_in = sb.h; np.h_out = sb.h; np.xn = sb.xn; np.w = Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            np.parts = fb.po; np.parts_ks = fb.kso; np.parts_stride = (long)b * D;
+            car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
+        }
+        lin(L + "feed_forward.w13.weight", sb.xn, 0, 0, fb.p13, 2 * Fh, D, fb.ks13);
+        car_launch_swiglu_parts(fb.p13, fb.ks13, (long)b * 2 * Fh, sb.mid, b, Fh, st); ++nk;
+        lin(L + "feed_forward.w2.weight", sb.mid, 0, 0, fb.p2, D, Fh, fb.ks2);
+    }
+    {   // h += last FFN output ; final norm
+        NormP np; memset(&np, 0, sizeof(np));
+        np.h_in = sb.h; np.h_out = sb.h; np.xn = sb.xn; np.w = Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps;
+        np.parts = fb.p2; np.parts_ks = fb.ks2; np.parts_stride = (long)b * D;
+        car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
+    }
+    lin("output.weight", sb.xn, 0, 0, fb.pl, V, D, fb.ksl);
+    car_launch_advance(sb.pos, sb.step, st); ++nk;
+    SampleP sp = sp_tmpl; sp.logits = fb.pl; sp.logits_ks = fb.ksl; sp.logits_stride = (long)b * V; sp.round_bf16 = 1;
+    car_launch_sample_greedy(&sp, st); ++nk;
+    c->n_dec_kernels = nk;
+    return 0;
+}
+
 static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b, int B, int S_max, int n_tok, int nsplit, bool use_ctrl,
                                float cs, const SampleP& sp_tmpl, hipStream_t st) {
     const car_config& g = c->cfg; const int mode = c->mode; const size_t e = c->esz;
@@ -720,10 +830,22 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
     sb.part = (float*)c->ws[10].p; sb.logits = logits; sb.pos = pos; sb.step = step; sb.cur = cur;
     const int nsteps = n_new - 1;
     c->stats.graph_used = 0;
+    FastBufs fb; memset(&fb, 0, sizeof(fb));
+    const bool fast = mode == CAR_BF16;
+    if (fast) {
+        fb.ksq = pick_ks(3 * D, D, b); fb.kso = pick_ks(D, D, b); fb.ks13 = pick_ks(2 * Fh, D, b); fb.ks2 = pick_ks(D, Fh, b); fb.ksl = pick_ks(V, D, b);
+        const size_t nq = (size_t)fb.ksq * b * 3 * D, no = (size_t)fb.kso * b * D, n13 = (size_t)fb.ks13 * b * 2 * Fh, n2 = (size_t)fb.ks2 * b * D, nl = (size_t)fb.ksl * b * V;
+        NEED(c, c->dec_parts, (nq + no + n13 + n2 + nl) * 4);
+        fb.pq = (float*)c->dec_parts.p; fb.po = fb.pq + nq; fb.p13 = fb.po + no; fb.p2 = fb.p13 + n13; fb.pl = fb.p2 + n2;
+    }
+    auto step_fn = [&]() {
+        if (fast) enqueue_decode_step_fast(c, sb, fb, b, S_max, n_tok, nsplit, use_control != 0, cs, spp, st);
+        else enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st);
+    };
     if (nsteps > 0) {
         char keyb[256];
         snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%p|%p", b, B, S_max, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
-                 c->ctrl[0].p, c->maskb.p, c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, (const void*)forced_tokens, (void*)logits_out);
+                 c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, (const void*)forced_tokens, (void*)logits_out);
         const std::string key(keyb);
         bool graph_ok = true;
         if (!c->gexec || c->gkey != key) {
@@ -731,7 +853,7 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_ok = false; (void)hipGetLastError(); }
             if (graph_ok) {
-                enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st);
+                step_fn();
                 if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) { graph_ok = false; (void)hipGetLastError(); }
             }
             if (graph_ok && hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0) != hipSuccess) { graph_ok = false; c->gexec = nullptr; (void)hipGetLastError(); }
@@ -742,7 +864,7 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
             for (int i = 0; i < nsteps; ++i) HIPCHK(c, hipGraphLaunch(c->gexec, st));
             c->stats.graph_used = 1;
         } else {
-            for (int i = 0; i < nsteps; ++i) enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st);
+            for (int i = 0; i < nsteps; ++i) step_fn();
         }
     }
     HIPCHK(c, hipEventRecord(c->ev_t2, st));

@@ -67,6 +67,7 @@ extern "C" void car_launch_layernorm(int mode, const void* x, const void* w, con
 // ------------------------------------------------------------------ RMSNorm with optional token gather and control add
 // reference: gpt_t2i.py:193-198 (norm), :445 (tok_embeddings gather), :463/:466 (control add)
 //   row r:  v = gather ? emb[idx[r]] : h_in[r]
+//           parts: v = rnd(v + rnd(sum_s parts[s][r]))   (residual add of a dec_linear output, decode fast path)
 //           add_mode 1 (decode):  v = rnd(v + rnd(cs * ctrl[r, *pos - T + 1]))
 //           add_mode 2 (prefill): same with control token 0, only on rows r % T == T-1 (ctrl batch = r / T)
 //           h_out[r] = v (if h_out);  xn[r] = rnd(rnd(v * rsqrt(mean(v^2)+eps)) * w)
@@ -74,34 +75,81 @@ struct NormP {
     const void* h_in; const void* emb; const int* idx; void* h_out; void* xn; const void* w;
     const void* ctrl; const int* pos; int add_mode; int T; int n_tok; float cs;
     int D; float eps;
+    const float* parts; int parts_ks; long parts_stride;   // residual branch as fp32 split-K partials [ks][rows][D] of dec_linear
 };
 template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(NormP p) {
+__device__ inline void ld4(const T* p, float (&v)[4]);
+template <> __device__ inline void ld4<float>(const float* p, float (&v)[4]) { const float4 u = *(const float4*)p; v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
+template <> __device__ inline void ld4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    const uint2 u = *(const uint2*)p;
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u); v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+template <typename T>
+__device__ inline void st4(T* p, const float (&v)[4]);
+template <> __device__ inline void st4<float>(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+template <> __device__ inline void st4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    uint2 u; u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *(uint2*)p = u;
+}
+
+// one block per row; each thread owns groups of 4 consecutive columns (D % 4 == 0), values stay in registers
+// (up to 4 groups per thread: D <= 16 * blockDim)
+template <typename T>
+__global__ __launch_bounds__(1024) void rmsnorm_kernel(NormP p) {
     __shared__ float sm[20];
-    extern __shared__ float rowbuf[];   // D floats
     const long r = blockIdx.x;
-    const int D = p.D;
+    const int D = p.D, ng = D >> 2;
     const T* src = p.idx ? (const T*)p.emb + (long)p.idx[r] * D : (const T*)p.h_in + r * D;
     const T* add = nullptr;
     if (p.add_mode == 1) add = (const T*)p.ctrl + (r * p.n_tok + (*p.pos - p.T + 1)) * D;
     else if (p.add_mode == 2 && (r % p.T) == p.T - 1) add = (const T*)p.ctrl + ((r / p.T) * (long)p.n_tok) * D;
+    float val[4][4];
     float ss = 0.f;
-    for (int i = threadIdx.x; i < D; i += blockDim.x) {
-        float v = ET<T>::ld(src + i);
-        if (add) v = ET<T>::rnd(v + ET<T>::rnd(p.cs * ET<T>::ld(add + i)));
-        rowbuf[i] = v;
-        ss += v * v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int gi = threadIdx.x + q * blockDim.x;
+        if (gi < ng) {
+            float v[4]; ld4<T>(src + gi * 4, v);
+            if (p.parts) {      // h = h + linear_out: the linear output (sum of split-K slices) is rounded to T first
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* pp = p.parts + r * D + gi * 4;
+                int s = 0;
+                for (; s + 4 <= p.parts_ks; s += 4) {
+                    const float4 a0 = *(const float4*)(pp + (s + 0) * p.parts_stride), a1 = *(const float4*)(pp + (s + 1) * p.parts_stride);
+                    const float4 a2 = *(const float4*)(pp + (s + 2) * p.parts_stride), a3 = *(const float4*)(pp + (s + 3) * p.parts_stride);
+                    a[0] += a0.x; a[1] += a0.y; a[2] += a0.z; a[3] += a0.w;  a[0] += a1.x; a[1] += a1.y; a[2] += a1.z; a[3] += a1.w;
+                    a[0] += a2.x; a[1] += a2.y; a[2] += a2.z; a[3] += a2.w;  a[0] += a3.x; a[1] += a3.y; a[2] += a3.z; a[3] += a3.w;
+                }
+                for (; s < p.parts_ks; ++s) { const float4 a0 = *(const float4*)(pp + s * p.parts_stride); a[0] += a0.x; a[1] += a0.y; a[2] += a0.z; a[3] += a0.w; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ET<T>::rnd(v[e] + ET<T>::rnd(a[e]));
+            }
+            if (add) {
+                float c[4]; ld4<T>(add + gi * 4, c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ET<T>::rnd(v[e] + ET<T>::rnd(p.cs * c[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { val[q][e] = v[e]; ss += v[e] * v[e]; }
+        }
     }
     const float rstd = rsqrtf(block_sum(ss, sm) / D + p.eps);
-    for (int i = threadIdx.x; i < D; i += blockDim.x) {
-        const float v = rowbuf[i];
-        if (p.h_out) ET<T>::st((T*)p.h_out + r * D + i, v);
-        ET<T>::st((T*)p.xn + r * D + i, ET<T>::rnd(v * rstd) * ET<T>::ld((const T*)p.w + i));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int gi = threadIdx.x + q * blockDim.x;
+        if (gi < ng) {
+            if (p.h_out) st4<T>((T*)p.h_out + r * D + gi * 4, val[q]);
+            float w[4], o[4]; ld4<T>((const T*)p.w + gi * 4, w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ET<T>::rnd(val[q][e] * rstd) * w[e];
+            st4<T>((T*)p.xn + r * D + gi * 4, o);
+        }
     }
 }
 extern "C" void car_launch_rmsnorm(int mode, const NormP* p, long rows, hipStream_t st) {
-    if (mode == 1) hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, dim3(rows), dim3(256), p->D * sizeof(float), st, *p);
-    else hipLaunchKernelGGL(rmsnorm_kernel<float>, dim3(rows), dim3(256), p->D * sizeof(float), st, *p);
+    int ng = p->D / 4, th = ((ng + 63) / 64) * 64; if (th > 1024) th = 1024; if (th < 64) th = 64;
+    if (mode == 1) hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, dim3(rows), dim3(th), 0, st, *p);
+    else hipLaunchKernelGGL(rmsnorm_kernel<float>, dim3(rows), dim3(th), 0, st, *p);
 }
 
 // ------------------------------------------------------------------ row softmax  S fp32 [rows, lds] -> P T [rows, ldp] (zero padded)
@@ -344,6 +392,36 @@ extern "C" void car_launch_swiglu(int mode, const void* in, void* out, long rows
     LAUNCH_T(mode, swiglu_kernel, dim3(g), dim3(256), st, in, out, rows, hidden);
 }
 
+// decode fast path: mid[m][k] = rnd(rnd(silu(rnd(sum_s a))) * rnd(sum_s c)) from the w13 split-K partials [ks][b][2*hidden]
+// (block-16 interleaved w1|w3 columns); 8 hidden units per thread, 16-byte bf16 store.  gpt_t2i.py:217 rounding points.
+__global__ __launch_bounds__(256) void swiglu_parts_kernel(const float* parts, int ks, long stride, bf16_t* out, int rows, int hidden) {
+    const int gpr = hidden >> 3;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)rows * gpr) return;
+    const int m = (int)(gid / gpr), k = (int)(gid - (long)m * gpr) * 8, col = (k >> 4) * 32 + (k & 15);
+    float a[8], g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; g[e] = 0.f; }
+    for (int s = 0; s < ks; ++s) {
+        const float* src = parts + s * stride + (long)m * 2 * hidden + col;
+        const float4 a0 = *(const float4*)src, a1 = *(const float4*)(src + 4), g0 = *(const float4*)(src + 16), g1 = *(const float4*)(src + 20);
+        a[0] += a0.x; a[1] += a0.y; a[2] += a0.z; a[3] += a0.w; a[4] += a1.x; a[5] += a1.y; a[6] += a1.z; a[7] += a1.w;
+        g[0] += g0.x; g[1] += g0.y; g[2] += g0.z; g[3] += g0.w; g[4] += g1.x; g[5] += g1.y; g[6] += g1.z; g[7] += g1.w;
+    }
+    unsigned o[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const float s0 = bf2f(f2bf(silu_f(bf2f(f2bf(a[e]))))) * bf2f(f2bf(g[e]));
+        const float s1 = bf2f(f2bf(silu_f(bf2f(f2bf(a[e + 1]))))) * bf2f(f2bf(g[e + 1]));
+        o[e >> 1] = (unsigned)f2bf(s0) | ((unsigned)f2bf(s1) << 16);
+    }
+    *(uint4*)(out + (long)m * hidden + k) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+extern "C" void car_launch_swiglu_parts(const float* parts, int ks, long stride, void* out, int rows, int hidden, hipStream_t st) {
+    const long n = (long)rows * (hidden >> 3);
+    hipLaunchKernelGGL(swiglu_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, st, parts, ks, stride, (bf16_t*)out, rows, hidden);
+}
+
 // ------------------------------------------------------------------ CFG mix + greedy argmax (generate.py:90,105; :59-74 greedy branch)
 // logits fp32 [b, V] (cond rows [0,B), uncond rows [B,2B)).  One block per image.
 //   mixed = use_mix ? u + (c - u) * scale : c;  token = lowest index of the maximum (torch.topk tie rule)
@@ -352,32 +430,47 @@ extern "C" void car_launch_swiglu(int mode, const void* in, void* out, long rows
 struct SampleP {
     const float* logits; int B, V, use_cfg; float cfg_scale; int cfg_interval;
     const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
+    int logits_ks; long logits_stride; int round_bf16;   // logits given as split-K partials [ks][b][V]; bf16 rounding of the sum (gpt_t2i.py:470)
 };
-__global__ __launch_bounds__(256) void sample_greedy_kernel(SampleP p) {
-    __shared__ float smv[4]; __shared__ int smi[4];
+// 4 consecutive logits of `row` starting at column j (V % 4 == 0)
+__device__ inline void sample_logit4(const SampleP& p, long row, int j, float (&v)[4]) {
+    if (p.logits_ks <= 0) { const float4 u = *(const float4*)(p.logits + row * p.V + j); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; return; }
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.logits_ks; ++s) {
+        const float4 u = *(const float4*)(p.logits + s * p.logits_stride + row * p.V + j);
+        a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = p.round_bf16 ? bf2f(f2bf(a[e])) : a[e];
+}
+__global__ __launch_bounds__(1024) void sample_greedy_kernel(SampleP p) {
+    __shared__ float smv[16]; __shared__ int smi[16];
     const int i = blockIdx.x, step = *p.step_ptr;
-    const float* c = p.logits + (long)i * p.V;
-    const float* u = p.use_cfg ? p.logits + (long)(i + p.B) * p.V : nullptr;
     // cfg_flag of decode_n_tokens: loop index = step-1; flag drops once (step-1) > cfg_interval
     const bool mix = p.use_cfg && !(p.cfg_interval > -1 && (step - 1) > p.cfg_interval);
     float best = -INFINITY; int bi = 0x7fffffff;
     float* lo = p.logits_out ? p.logits_out + ((long)i * p.n_new + step) * p.V : nullptr;
-    for (int j = threadIdx.x; j < p.V; j += blockDim.x) {
-        float v = c[j];
-        if (mix) v = u[j] + (c[j] - u[j]) * p.cfg_scale;
-        if (lo) lo[j] = v;
-        if (v > best) { best = v; bi = j; }   // strided ascending j per thread: first max kept
+    for (int j = threadIdx.x * 4; j < p.V; j += blockDim.x * 4) {
+        float v[4]; sample_logit4(p, i, j, v);
+        if (mix) {
+            float u[4]; sample_logit4(p, i + p.B, j, u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = u[e] + (v[e] - u[e]) * p.cfg_scale;
+        }
+        if (lo) *(float4*)(lo + j) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (v[e] > best) { best = v[e]; bi = j + e; }   // ascending j per thread: first max kept
     }
     // wave reduce (max value, then min index)
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    const int w = threadIdx.x >> 6;
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) { smv[w] = best; smi[w] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) if (smv[k] > best || (smv[k] == best && smi[k] < bi)) { best = smv[k]; bi = smi[k]; }
+        for (int k = 1; k < nw; ++k) if (smv[k] > best || (smv[k] == best && smi[k] < bi)) { best = smv[k]; bi = smi[k]; }
         p.out_tokens[(long)i * p.n_new + step] = bi;
         const int fb = p.forced ? p.forced[(long)i * p.n_new + step] : bi;
         p.cur_tok[i] = fb;
@@ -385,7 +478,8 @@ __global__ __launch_bounds__(256) void sample_greedy_kernel(SampleP p) {
     }
 }
 extern "C" void car_launch_sample_greedy(const SampleP* p, hipStream_t st) {
-    hipLaunchKernelGGL(sample_greedy_kernel, dim3(p->B), dim3(256), 0, st, *p);
+    int th = p->V / 4; th = ((th + 63) / 64) * 64; if (th > 1024) th = 1024; if (th < 64) th = 64;
+    hipLaunchKernelGGL(sample_greedy_kernel, dim3(p->B), dim3(th), 0, st, *p);
 }
 
 // step bookkeeping: pos += 1, step += 1 (device-side so a captured hipGraph can be replayed)

@@ -1,0 +1,49 @@
+"""Data-parallel edges of the path.  The reference shards images across ranks with
+no collective inside generation (autoregressive/sample/sample_t2i_ddp.py:127-170, index
+i*world+rank at :131); north_star adds ONE broadcast of text/control inputs before generation
+and a gather of tokens after it.  On ROCm backend "nccl" is RCCL (xGMI); the same code runs on
+gloo for the CPU tests.  `dist` may be None (single process): every function degrades to a no-op.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def shard_slice(G: int, world: int, rank: int) -> slice:
+    """Strided shard r, r+W, r+2W, ... (mirrors sample_t2i_ddp.py:131)."""
+    return slice(rank, G, world)
+
+
+def pad_to_world(G: int, world: int) -> int:
+    """'sample a bit more than we need' (sample_t2i_ddp.py:116-123): round the global batch up."""
+    return (G + world - 1) // world * world
+
+
+def broadcast_inputs(dist, device, rank: int, G: int, H: int, W: int, T: int, cap: int, img, emb, mask, src: int = 0):
+    """Rank `src` holds img [G,3,H,W] bf16, emb [G,T,cap] bf16, mask [G,T] int64; everyone gets all
+    three with a single broadcast of one packed byte buffer (payloads are tens of MB: latency-bound,
+    so one large message beats three)."""
+    n_img, n_emb, n_mask = G * 3 * H * W * 2, G * T * cap * 2, G * T * 8
+    if rank == src:
+        buf = torch.cat([img.contiguous().view(torch.uint8).reshape(-1), emb.contiguous().view(torch.uint8).reshape(-1),
+                         mask.contiguous().view(torch.uint8).reshape(-1)]).to(device)
+    else:
+        buf = torch.empty(n_img + n_emb + n_mask, dtype=torch.uint8, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(buf, src=src)
+    img = buf[:n_img].view(torch.bfloat16).view(G, 3, H, W)
+    emb = buf[n_img:n_img + n_emb].view(torch.bfloat16).view(G, T, cap)
+    mask = buf[n_img + n_emb:].view(torch.int64).view(G, T)
+    return img, emb, mask
+
+
+def gather_tokens(dist, local_tokens: torch.Tensor) -> torch.Tensor:
+    """all_gather of the per-rank token blocks, re-interleaved to global image order
+    (inverse of shard_slice)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_tokens
+    world = dist.get_world_size()
+    parts = [torch.empty_like(local_tokens) for _ in range(world)]
+    dist.all_gather(parts, local_tokens.contiguous())
+    out = torch.stack(parts, dim=1)                       # [per_rank, world, N]: image r + W*i lives at [i, r]
+    return out.reshape(-1, local_tokens.shape[-1])

@@ -1,0 +1,58 @@
+"""CPU: the C-ABI library loads and exports every symbol include/controlar_hip.h declares;
+argument validation that needs no GPU works; the product never imports the oracle."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from controlar_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "controlar_hip.h")).read()
+    declared = set(re.findall(r"\b(car_[a-z_]+)\s*\(", hdr))
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.car_abi_version() == L.CAR_ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    assert C.sizeof(L.CarConfig) == 4 * (2 + 5 + 3 + 2 + 6 + 2 + 6 + 8 + 1 + 8)
+    assert C.sizeof(L.CarSampling) == 56
+    assert C.sizeof(L.CarStats) == 8 * 4 + 4 * 8
+
+
+def test_create_rejects_bad_config_without_gpu():
+    lib = L.load()
+    h = C.c_void_p()
+    cc = L.CarConfig()
+    cc.abi_version = 99
+    assert lib.car_create(C.byref(h), C.byref(cc)) != 0
+    assert b"abi_version" in lib.car_last_error(None)
+    cc.abi_version = L.CAR_ABI_VERSION
+    assert lib.car_create(C.byref(h), C.byref(cc)) != 0      # zero dims
+    assert lib.car_create(None, None) != 0
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "controlar_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                src = open(os.path.join(dp, f)).read()
+                assert "controlar_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from controlar_amd import config as Cfg
+    from controlar_amd.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine(Cfg.tiny_t2i(), "bf16")

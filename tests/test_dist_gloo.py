@@ -1,0 +1,62 @@
+"""CPU, world_size 2 over gloo: the data-parallel edges (broadcast -> shard -> gather) used by bench.py
+at N>1 reproduce the single-process result exactly."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, G, q):
+    import torch.distributed as dist
+    from controlar_amd import synth
+    from controlar_amd.dist import broadcast_inputs, shard_slice, gather_tokens
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H = W = 32; T, cap = 12, 64
+    if rank == 0:
+        img = synth.canny_like_control(G, H, W).to(torch.bfloat16)
+        emb, mask = synth.text_embeddings(G, T, cap); emb = emb.to(torch.bfloat16)
+    else:
+        img = emb = mask = None
+    img, emb, mask = broadcast_inputs(dist, torch.device("cpu"), rank, G, H, W, T, cap, img, emb, mask)
+    sl = shard_slice(G, world, rank)
+    # stand-in for the per-rank generate(): a deterministic function of this rank's shard only
+    local = (img[sl].float().sum(dim=(1, 2, 3)).round().to(torch.int32)[:, None] +
+             mask[sl].sum(dim=1).to(torch.int32)[:, None] + torch.arange(5, dtype=torch.int32)[None])
+    allt = gather_tokens(dist, local)
+    q.put((rank, allt.clone(), emb.float().abs().sum().item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_shard_gather_world2():
+    from controlar_amd import synth
+    G, world = 6, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, G, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in ps]
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    img = synth.canny_like_control(G, 32, 32).to(torch.bfloat16)
+    emb, mask = synth.text_embeddings(G, 12, 64)
+    want = (img.float().sum(dim=(1, 2, 3)).round().to(torch.int32)[:, None] + mask.sum(dim=1).to(torch.int32)[:, None] +
+            torch.arange(5, dtype=torch.int32)[None])
+    for rank, allt, esum in res:
+        assert torch.equal(allt, want), rank                      # global order restored on every rank
+        assert abs(esum - emb.to(torch.bfloat16).float().abs().sum().item()) < 1e-3
+
+
+def test_shard_helpers():
+    from controlar_amd.dist import shard_slice, pad_to_world
+    idx = list(range(10))
+    got = sorted(sum([idx[shard_slice(10, 4, r)] for r in range(4)], []))
+    assert got == idx
+    assert pad_to_world(10, 4) == 12 and pad_to_world(8, 4) == 8

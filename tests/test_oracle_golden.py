@@ -74,11 +74,11 @@ def test_oracle_bf16_mode_tracks_reference_bf16(golden_dir):
 
 
 def test_resize_restatements_match_torch():
-    x = torch.randn(2, 3, 64, 96)
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(3))
     ref = torch.nn.functional.interpolate(x, size=(56, 84), mode="bicubic", align_corners=True)
-    np.testing.assert_allclose(O.bicubic_resize(x, 56, 84, True).numpy(), ref.numpy(), atol=2e-6)
+    np.testing.assert_allclose(O.bicubic_resize(x, 56, 84, True).numpy(), ref.numpy(), atol=1e-5)
     ref = torch.nn.functional.interpolate(x, size=(40, 50), mode="bicubic", align_corners=False)
-    np.testing.assert_allclose(O.bicubic_resize(x, 40, 50, False).numpy(), ref.numpy(), atol=2e-6)
+    np.testing.assert_allclose(O.bicubic_resize(x, 40, 50, False).numpy(), ref.numpy(), atol=1e-5)
     for (o, i) in [(448, 512), (672, 768), (112, 128), (56, 64)]:
         ref = torch.nn.functional.interpolate(torch.arange(i, dtype=torch.float32).view(1, 1, 1, i), size=(1, o), mode="nearest")
         assert torch.equal(O.nearest_src_index(o, i), ref.view(-1).long())

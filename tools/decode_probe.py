@@ -1,0 +1,28 @@
+"""GPU probe: decode-step time vs batch for the XL model (weights loaded once).  Not a test."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from controlar_amd import config as C, synth
+from controlar_amd.engine import Engine
+
+model = sys.argv[1] if len(sys.argv) > 1 else "xl"
+batches = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "2,8,16,32,64").split(",")]
+n_new = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+cfg = C.xl_t2i(1024) if model == "xl" else C.b_t2i(1024)
+t0 = time.time()
+gsd, _ = synth.path_state_dicts(cfg, 0)
+eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+print("load %.1fs" % (time.time() - t0), flush=True)
+for B in batches:
+    img = synth.canny_like_control(B, 512, 512).to(torch.bfloat16).cuda()
+    emb, mask = synth.text_embeddings(B, 120, 2048)
+    emb = emb.to(torch.bfloat16).cuda(); mask = mask.cuda()
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.time()
+        eng.encode_control(img); torch.cuda.synchronize(); t1 = time.time()
+        eng.generate(emb, n_new, mask, cfg_scale=1.0); torch.cuda.synchronize(); t2 = time.time()
+        st = eng.stats()
+    ms = st["decode_ms"] / st["decode_steps"]
+    gbs = st["decode_algo_bytes"] / st["decode_steps"] / (ms * 1e-3) / 1e9
+    print(json.dumps(dict(B=B, n_new=n_new, enc_ms=(t1 - t0) * 1e3, gen_ms=(t2 - t1) * 1e3, prefill_ms=st["prefill_ms"], ms_per_step=ms,
+                          algo_GBps=gbs, frac=gbs / 8000, kernels=st["decode_kernels_per_step"])), flush=True)
