@@ -83,6 +83,7 @@ struct Wt { void* p = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
 struct car_ctx {
     car_config cfg; int mode = 0; size_t esz = 4;
     std::string err;
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
     std::unordered_map<std::string, Wt> w;            // packed weights by (reference) name, element type T unless noted
     std::unordered_map<std::string, std::vector<float>> host_keep;   // host fp32 copies needed later (pos-emb, w1/w3 halves)
@@ -140,6 +141,9 @@ extern "C" int car_create(car_ctx** out, const car_config* cfg) {
     c->cfg = *cfg; c->mode = cfg->mode; c->esz = cfg->mode == CAR_BF16 ? 2 : 4;
     memset(&c->stats, 0, sizeof(c->stats));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess || hipEventCreate(&c->ev_t2) != hipSuccess) {
@@ -180,7 +184,8 @@ extern "C" void car_destroy(car_ctx* c) {
     c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
     c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
-    (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->stream2);
+    (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -590,56 +595,66 @@ static int pick_ks(int N, int K, int b) {
 
 struct FastBufs { float *pq, *po, *p13, *p2, *pl; int ksq, kso, ks13, ks2, ksl; };
 
-// bf16 fast path: 7 kernels per layer, every linear is a dec_linear whose split-K partials are summed by its consumer
-static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const FastBufs& fb, int b, int S_max, int n_tok, int nsplit, bool use_ctrl,
-                                    float cs, const SampleP& sp_tmpl, hipStream_t st) {
+// A group = a contiguous slice [b0, b0+bg) of the sequences decoded as its own dependency chain.  With two
+// groups the captured step has two parallel branches: one chain's bandwidth-bound attention overlaps the
+// other chain's latency-bound small kernels (each chain re-reads the weights; they mostly hit the 256 MiB MALL).
+struct Grp { int b0, bg, nsplit; int *pos, *step; FastBufs fb; SampleP sp; float* attn_part; };
+
+// bf16 fast path: 8 kernels per layer, every linear is a dec_linear whose split-K partials are summed by its consumer
+static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& gr, int b_total, int S_max, int n_tok, bool use_ctrl,
+                                    float cs, hipStream_t st) {
     const car_config& g = c->cfg; const size_t e = c->esz;
     const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, li = g.n_layer / 3, V = g.vocab_size;
-    const size_t kv_layer = (size_t)b * Hn * S_max * 64;
+    const int b = gr.bg, b0 = gr.b0, nsplit = gr.nsplit;
+    const FastBufs& fb = gr.fb;
+    const size_t kv_layer = (size_t)b_total * Hn * S_max * 64, kv_off = (size_t)b0 * Hn * S_max * 64;
+    void* h = off(sb.h, (size_t)b0 * D, e); void* xn = off(sb.xn, (size_t)b0 * D, e); void* att = off(sb.att, (size_t)b0 * D, e);
+    void* mid = off(sb.mid, (size_t)b0 * Fh, e);
+    const unsigned char* mask = (const unsigned char*)c->maskb.p + (size_t)b0 * g.cls_token_num;
     int nk = 0;
-    auto lin = [&](const std::string& wname, const void* X, int xmode, int xks, float* part, int N, int K, int KS) {
-        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + "#pk"); lp.X = X; lp.part = part; lp.xmode = xmode; lp.xks = xks; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS;
+    auto lin = [&](const std::string& wname, const void* X, float* part, int N, int K, int KS) {
+        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + "#pk"); lp.X = X; lp.part = part; lp.xmode = 0; lp.xks = 0; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS;
         car_launch_dec_linear(&lp, st); ++nk;
     };
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
         {   // [token gather | + previous layer's FFN output] (+ control add) -> h ; attention_norm -> xn
             NormP np; memset(&np, 0, sizeof(np));
-            np.h_in = sb.h; np.h_out = sb.h; np.xn = sb.xn; np.w = Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
-            if (l == 0) { np.emb = Wp(c, "tok_embeddings.weight"); np.idx = sb.cur; }
+            np.h_in = h; np.h_out = h; np.xn = xn; np.w = Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            if (l == 0) { np.emb = Wp(c, "tok_embeddings.weight"); np.idx = sb.cur + b0; }
             else { np.parts = fb.p2; np.parts_ks = fb.ks2; np.parts_stride = (long)b * D; }
-            if (use_ctrl && l % li == 0 && l / li < 3) { np.add_mode = 1; np.ctrl = c->ctrl[l / li].p; np.pos = sb.pos; np.T = g.cls_token_num; np.n_tok = n_tok; np.cs = cs; }
+            if (use_ctrl && l % li == 0 && l / li < 3) { np.add_mode = 1; np.ctrl = off(c->ctrl[l / li].p, (size_t)b0 * n_tok * D, e); np.pos = gr.pos; np.T = g.cls_token_num; np.n_tok = n_tok; np.cs = cs; }
             car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
         }
-        lin(L + "attention.wqkv.weight", sb.xn, 0, 0, fb.pq, 3 * D, D, fb.ksq);
+        lin(L + "attention.wqkv.weight", xn, fb.pq, 3 * D, D, fb.ksq);
         {
             AttnP ap; memset(&ap, 0, sizeof(ap));
-            ap.kcache = off(c->kv.p, (size_t)(2 * l) * kv_layer, e); ap.vcache = off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e);
-            ap.rope = c->rope; ap.pos = sb.pos; ap.emb_mask = (const unsigned char*)c->maskb.p; ap.out = sb.att; ap.part = sb.part;
+            ap.kcache = off(c->kv.p, (size_t)(2 * l) * kv_layer + kv_off, e); ap.vcache = off(c->kv.p, (size_t)(2 * l + 1) * kv_layer + kv_off, e);
+            ap.rope = c->rope; ap.pos = gr.pos; ap.emb_mask = mask; ap.out = att; ap.part = gr.attn_part;
             ap.H = Hn; ap.S_max = S_max; ap.T = g.cls_token_num; ap.dim = D; ap.nsplit = nsplit;
             ap.qkv_parts = fb.pq; ap.qkv_ks = fb.ksq; ap.qkv_stride = (long)b * 3 * D;
             car_launch_dec_attn(CAR_BF16, &ap, b, st); nk += nsplit > 1 ? 2 : 1;
         }
-        lin(L + "attention.wo.weight", sb.att, 0, 0, fb.po, D, D, fb.kso);
+        lin(L + "attention.wo.weight", att, fb.po, D, D, fb.kso);
         {   // h += attention output ; ffn_norm -> xn
             NormP np; memset(&np, 0, sizeof(np));
-            np.h_in = sb.h; np.h_out = sb.h; np.xn = sb.xn; np.w = Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            np.h_in = h; np.h_out = h; np.xn = xn; np.w = Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps;
             np.parts = fb.po; np.parts_ks = fb.kso; np.parts_stride = (long)b * D;
             car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
         }
-        lin(L + "feed_forward.w13.weight", sb.xn, 0, 0, fb.p13, 2 * Fh, D, fb.ks13);
-        car_launch_swiglu_parts(fb.p13, fb.ks13, (long)b * 2 * Fh, sb.mid, b, Fh, st); ++nk;
-        lin(L + "feed_forward.w2.weight", sb.mid, 0, 0, fb.p2, D, Fh, fb.ks2);
+        lin(L + "feed_forward.w13.weight", xn, fb.p13, 2 * Fh, D, fb.ks13);
+        car_launch_swiglu_parts(fb.p13, fb.ks13, (long)b * 2 * Fh, mid, b, Fh, st); ++nk;
+        lin(L + "feed_forward.w2.weight", mid, fb.p2, D, Fh, fb.ks2);
     }
     {   // h += last FFN output ; final norm
         NormP np; memset(&np, 0, sizeof(np));
-        np.h_in = sb.h; np.h_out = sb.h; np.xn = sb.xn; np.w = Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps;
+        np.h_in = h; np.h_out = h; np.xn = xn; np.w = Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps;
         np.parts = fb.p2; np.parts_ks = fb.ks2; np.parts_stride = (long)b * D;
         car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
     }
-    lin("output.weight", sb.xn, 0, 0, fb.pl, V, D, fb.ksl);
-    car_launch_advance(sb.pos, sb.step, st); ++nk;
-    SampleP sp = sp_tmpl; sp.logits = fb.pl; sp.logits_ks = fb.ksl; sp.logits_stride = (long)b * V; sp.round_bf16 = 1;
+    lin("output.weight", xn, fb.pl, V, D, fb.ksl);
+    car_launch_advance(gr.pos, gr.step, st); ++nk;
+    SampleP sp = gr.sp; sp.logits = fb.pl; sp.logits_ks = fb.ksl; sp.logits_stride = (long)b * V; sp.round_bf16 = 1;
     car_launch_sample_greedy(&sp, st); ++nk;
     c->n_dec_kernels = nk;
     return 0;
@@ -755,8 +770,8 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
     }
     int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 8;
     {
-        int init[2] = {T, 0};    // after prefill the first decode step runs at input_pos = T, sampling token index 1
-        HIPCHK(c, hipMemcpyAsync(pos, init, 8, hipMemcpyHostToDevice, st));
+        int init[4] = {T, 0, T, 0};    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
+        HIPCHK(c, hipMemcpyAsync(pos, init, 16, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
 
@@ -830,22 +845,55 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
     sb.part = (float*)c->ws[10].p; sb.logits = logits; sb.pos = pos; sb.step = step; sb.cur = cur;
     const int nsteps = n_new - 1;
     c->stats.graph_used = 0;
-    FastBufs fb; memset(&fb, 0, sizeof(fb));
     const bool fast = mode == CAR_BF16;
+    // two concurrent chains when the batch is large enough and rows are group-separable (no CFG pairing across halves)
+    const int NG = (fast && !use_cfg && b >= 32 && !getenv("CAR_SINGLE_CHAIN")) ? 2 : 1;
+    Grp grp[2]; memset(grp, 0, sizeof(grp));
     if (fast) {
-        fb.ksq = pick_ks(3 * D, D, b); fb.kso = pick_ks(D, D, b); fb.ks13 = pick_ks(2 * Fh, D, b); fb.ks2 = pick_ks(D, Fh, b); fb.ksl = pick_ks(V, D, b);
-        const size_t nq = (size_t)fb.ksq * b * 3 * D, no = (size_t)fb.kso * b * D, n13 = (size_t)fb.ks13 * b * 2 * Fh, n2 = (size_t)fb.ks2 * b * D, nl = (size_t)fb.ksl * b * V;
-        NEED(c, c->dec_parts, (nq + no + n13 + n2 + nl) * 4);
-        fb.pq = (float*)c->dec_parts.p; fb.po = fb.pq + nq; fb.p13 = fb.po + no; fb.p2 = fb.p13 + n13; fb.pl = fb.p2 + n2;
+        size_t tot = 0; size_t sizes[2][5];
+        for (int gi = 0; gi < NG; ++gi) {
+            Grp& gr = grp[gi];
+            gr.b0 = gi == 0 ? 0 : (b + 1) / 2; gr.bg = NG == 1 ? b : (gi == 0 ? (b + 1) / 2 : b - (b + 1) / 2);
+            const int bg = gr.bg;
+            gr.nsplit = 1; { const int wg = bg * Hn; while (wg * gr.nsplit < 1024 && gr.nsplit < 16) gr.nsplit *= 2; }
+            FastBufs& f = gr.fb;
+            f.ksq = pick_ks(3 * D, D, bg); f.kso = pick_ks(D, D, bg); f.ks13 = pick_ks(2 * Fh, D, bg); f.ks2 = pick_ks(D, Fh, bg); f.ksl = pick_ks(V, D, bg);
+            sizes[gi][0] = (size_t)f.ksq * bg * 3 * D; sizes[gi][1] = (size_t)f.kso * bg * D; sizes[gi][2] = (size_t)f.ks13 * bg * 2 * Fh;
+            sizes[gi][3] = (size_t)f.ks2 * bg * D; sizes[gi][4] = (size_t)f.ksl * bg * V;
+            for (int k = 0; k < 5; ++k) tot += sizes[gi][k];
+            tot += (size_t)bg * Hn * gr.nsplit * 66;
+        }
+        NEED(c, c->dec_parts, tot * 4);
+        float* pbase = (float*)c->dec_parts.p;
+        for (int gi = 0; gi < NG; ++gi) {
+            Grp& gr = grp[gi]; FastBufs& f = gr.fb;
+            f.pq = pbase; pbase += sizes[gi][0]; f.po = pbase; pbase += sizes[gi][1]; f.p13 = pbase; pbase += sizes[gi][2];
+            f.p2 = pbase; pbase += sizes[gi][3]; f.pl = pbase; pbase += sizes[gi][4];
+            gr.attn_part = pbase; pbase += (size_t)gr.bg * Hn * gr.nsplit * 66;
+            gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: pos0, step0, pos1, step1
+            gr.sp = spp; gr.sp.B = use_cfg ? B : gr.bg; gr.sp.step_ptr = gr.step;   // under CFG (single chain) rows are [cond B | uncond B]
+            gr.sp.out_tokens = (int*)c->tok_out.p + (size_t)gr.b0 * n_new; gr.sp.cur_tok = cur + gr.b0;
+            gr.sp.forced = forced_tokens ? forced_tokens + (size_t)gr.b0 * n_new : nullptr;
+            gr.sp.logits_out = logits_out ? logits_out + (size_t)gr.b0 * n_new * V : nullptr;
+        }
     }
+    bool capturing = false;
     auto step_fn = [&]() {
-        if (fast) enqueue_decode_step_fast(c, sb, fb, b, S_max, n_tok, nsplit, use_control != 0, cs, spp, st);
-        else enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st);
+        if (!fast) { enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st); return; }
+        if (NG == 2 && capturing) {      // fork a second branch inside the capture
+            (void)hipEventRecord(c->ev_fork, st); (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+            enqueue_decode_step_fast(c, sb, grp[0], b, S_max, n_tok, use_control != 0, cs, st);
+            enqueue_decode_step_fast(c, sb, grp[1], b, S_max, n_tok, use_control != 0, cs, c->stream2);
+            (void)hipEventRecord(c->ev_join, c->stream2); (void)hipStreamWaitEvent(st, c->ev_join, 0);
+        } else {
+            for (int gi = 0; gi < NG; ++gi) enqueue_decode_step_fast(c, sb, grp[gi], b, S_max, n_tok, use_control != 0, cs, st);
+        }
+        c->n_dec_kernels *= (NG == 2 ? 2 : 1);
     };
     if (nsteps > 0) {
         char keyb[256];
         snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%p|%p", b, B, S_max, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
-                 c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, (const void*)forced_tokens, (void*)logits_out);
+                 c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval * 4 + NG, (const void*)forced_tokens, (void*)logits_out);
         const std::string key(keyb);
         bool graph_ok = true;
         if (!c->gexec || c->gkey != key) {
@@ -853,7 +901,7 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_ok = false; (void)hipGetLastError(); }
             if (graph_ok) {
-                step_fn();
+                capturing = true; step_fn(); capturing = false;
                 if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) { graph_ok = false; (void)hipGetLastError(); }
             }
             if (graph_ok && hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0) != hipSuccess) { graph_ok = false; c->gexec = nullptr; (void)hipGetLastError(); }
