@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -83,11 +84,11 @@ struct Wt { void* p = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
 struct car_ctx {
     car_config cfg; int mode = 0; size_t esz = 4;
     std::string err;
-    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t streamx[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_joinx[3] = {nullptr, nullptr, nullptr};
     hipStream_t stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
     std::unordered_map<std::string, Wt> w;            // packed weights by (reference) name, element type T unless noted
     std::unordered_map<std::string, std::vector<float>> host_keep;   // host fp32 copies needed later (pos-emb, w1/w3 halves)
-    bool finalized = false;
+    bool finalized = false, has_gpt = false;
     // cached tables
     std::map<std::pair<int, int>, void*> pos_cache;   // (gh,gw) -> T [1+gh*gw, D]
     struct ResizeTab { int* iy; int* ix; float* wy; float* wx; };
@@ -141,9 +142,13 @@ extern "C" int car_create(car_ctx** out, const car_config* cfg) {
     c->cfg = *cfg; c->mode = cfg->mode; c->esz = cfg->mode == CAR_BF16 ? 2 : 4;
     memset(&c->stats, 0, sizeof(c->stats));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->streamx[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->streamx[1], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->streamx[2], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_joinx[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_joinx[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_joinx[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess || hipEventCreate(&c->ev_t2) != hipSuccess) {
@@ -184,8 +189,9 @@ extern "C" void car_destroy(car_ctx* c) {
     c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
     c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
-    (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->stream2);
-    (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
+    (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i < 3; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); }
+    (void)hipEventDestroy(c->ev_fork);
     delete c;
 }
 
@@ -359,8 +365,13 @@ extern "C" int car_finalize_weights(car_ctx* c) {
     }
     std::string missing;
     int nmiss = 0;
-    for (auto& r : req) if (!Wp(c, r)) { if (nmiss < 6) missing += r + " "; ++nmiss; }
-    if (c->host_keep.find("adapter.model.embeddings.position_embeddings") == c->host_keep.end()) { missing += "adapter.model.embeddings.position_embeddings "; ++nmiss; }
+    // a context may serve only decode_code (VQ weights alone) — the reference keeps GPT and VQ as separate modules
+    const bool vq_only = Wp(c, "quantize.embedding.weight") && !Wp(c, "tok_embeddings.weight") && !Wp(c, "output.weight");
+    c->has_gpt = !vq_only;
+    if (!vq_only) {
+        for (auto& r : req) if (!Wp(c, r)) { if (nmiss < 6) missing += r + " "; ++nmiss; }
+        if (c->host_keep.find("adapter.model.embeddings.position_embeddings") == c->host_keep.end()) { missing += "adapter.model.embeddings.position_embeddings "; ++nmiss; }
+    }
     // the VQ decoder is optional as a group (a context may serve generate() only) but must be complete if present
     if (Wp(c, "quantize.embedding.weight")) {
         int last = 0;
@@ -487,6 +498,7 @@ static void fence_out(car_ctx* c, hipStream_t caller) { (void)hipEventRecord(c->
 extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype, int32_t B, int32_t H, int32_t W, void* out, void* stream_) {
     if (!c) return -1;
     if (!c->finalized) FAIL(c, "car_encode_control: call car_finalize_weights first");
+    if (!c->has_gpt) FAIL(c, "car_encode_control: this context holds VQ weights only");
     if (!img || B <= 0 || H < 16 || W < 16) FAIL(c, "car_encode_control: bad arguments");
     if (img_dtype != CAR_DT_F32 && img_dtype != CAR_DT_BF16) FAIL(c, "car_encode_control: image dtype must be F32 or BF16");
     const car_config& g = c->cfg;
@@ -711,6 +723,7 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
                             float* logits_out, void* stream_) {
     if (!c) return -1;
     if (!c->finalized) FAIL(c, "car_generate: call car_finalize_weights first");
+    if (!c->has_gpt) FAIL(c, "car_generate: this context holds VQ weights only");
     if (!text_emb || !sp || !out_tokens || B <= 0 || n_new <= 0) FAIL(c, "car_generate: bad arguments");
     if (text_dtype != CAR_DT_F32 && text_dtype != CAR_DT_BF16) FAIL(c, "car_generate: text dtype must be F32 or BF16");
     const car_config& g = c->cfg;
@@ -770,8 +783,8 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
     }
     int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 8;
     {
-        int init[4] = {T, 0, T, 0};    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
-        HIPCHK(c, hipMemcpyAsync(pos, init, 16, hipMemcpyHostToDevice, st));
+        int init[8] = {T, 0, T, 0, T, 0, T, 0};    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
+        HIPCHK(c, hipMemcpyAsync(pos, init, 32, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
 
@@ -847,13 +860,17 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
     c->stats.graph_used = 0;
     const bool fast = mode == CAR_BF16;
     // two concurrent chains when the batch is large enough and rows are group-separable (no CFG pairing across halves)
-    const int NG = (fast && !use_cfg && b >= 32 && !getenv("CAR_SINGLE_CHAIN")) ? 2 : 1;
-    Grp grp[2]; memset(grp, 0, sizeof(grp));
+    // chains of <= 64 sequences (the dec_linear<4> sweet spot), at most 4
+    int NG = (fast && !use_cfg && b >= 32) ? (b <= 64 ? 2 : (b + 63) / 64) : 1;
+    if (NG > 4) NG = 4;
+    if (NG > 1) { const char* ev = getenv("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 4 && b / v >= 8) NG = v; } }
+    if (getenv("CAR_SINGLE_CHAIN")) NG = 1;
+    Grp grp[4]; memset(grp, 0, sizeof(grp));
     if (fast) {
-        size_t tot = 0; size_t sizes[2][5];
+        size_t tot = 0; size_t sizes[4][5];
         for (int gi = 0; gi < NG; ++gi) {
             Grp& gr = grp[gi];
-            gr.b0 = gi == 0 ? 0 : (b + 1) / 2; gr.bg = NG == 1 ? b : (gi == 0 ? (b + 1) / 2 : b - (b + 1) / 2);
+            gr.b0 = (int)((long)b * gi / NG); gr.bg = (int)((long)b * (gi + 1) / NG) - gr.b0;
             const int bg = gr.bg;
             gr.nsplit = 1; { const int wg = bg * Hn; while (wg * gr.nsplit < 1024 && gr.nsplit < 16) gr.nsplit *= 2; }
             FastBufs& f = gr.fb;
@@ -870,7 +887,7 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
             f.pq = pbase; pbase += sizes[gi][0]; f.po = pbase; pbase += sizes[gi][1]; f.p13 = pbase; pbase += sizes[gi][2];
             f.p2 = pbase; pbase += sizes[gi][3]; f.pl = pbase; pbase += sizes[gi][4];
             gr.attn_part = pbase; pbase += (size_t)gr.bg * Hn * gr.nsplit * 66;
-            gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: pos0, step0, pos1, step1
+            gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: (pos, step) x 4 chains, then cur_tok
             gr.sp = spp; gr.sp.B = use_cfg ? B : gr.bg; gr.sp.step_ptr = gr.step;   // under CFG (single chain) rows are [cond B | uncond B]
             gr.sp.out_tokens = (int*)c->tok_out.p + (size_t)gr.b0 * n_new; gr.sp.cur_tok = cur + gr.b0;
             gr.sp.forced = forced_tokens ? forced_tokens + (size_t)gr.b0 * n_new : nullptr;
@@ -880,15 +897,18 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
     bool capturing = false;
     auto step_fn = [&]() {
         if (!fast) { enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st); return; }
-        if (NG == 2 && capturing) {      // fork a second branch inside the capture
-            (void)hipEventRecord(c->ev_fork, st); (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+        if (NG >= 2 && capturing) {      // fork NG-1 extra branches inside the capture
+            (void)hipEventRecord(c->ev_fork, st);
+            for (int gi = 1; gi < NG; ++gi) (void)hipStreamWaitEvent(c->streamx[gi - 1], c->ev_fork, 0);
             enqueue_decode_step_fast(c, sb, grp[0], b, S_max, n_tok, use_control != 0, cs, st);
-            enqueue_decode_step_fast(c, sb, grp[1], b, S_max, n_tok, use_control != 0, cs, c->stream2);
-            (void)hipEventRecord(c->ev_join, c->stream2); (void)hipStreamWaitEvent(st, c->ev_join, 0);
+            for (int gi = 1; gi < NG; ++gi) {
+                enqueue_decode_step_fast(c, sb, grp[gi], b, S_max, n_tok, use_control != 0, cs, c->streamx[gi - 1]);
+                (void)hipEventRecord(c->ev_joinx[gi - 1], c->streamx[gi - 1]); (void)hipStreamWaitEvent(st, c->ev_joinx[gi - 1], 0);
+            }
         } else {
             for (int gi = 0; gi < NG; ++gi) enqueue_decode_step_fast(c, sb, grp[gi], b, S_max, n_tok, use_control != 0, cs, st);
         }
-        c->n_dec_kernels *= (NG == 2 ? 2 : 1);
+        c->n_dec_kernels *= NG;
     };
     if (nsteps > 0) {
         char keyb[256];

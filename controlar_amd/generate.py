@@ -1,0 +1,31 @@
+"""generate() with the reference signature (autoregressive/models/generate.py:134-204), running the whole
+loop in libcontrolar_hip.so.  Callers that keep working unchanged: sample_t2i.py:163, sample_t2i_MR.py:184,
+test_t2i.py:220, demo/model.py:156,250."""
+from __future__ import annotations
+
+import torch
+
+from .models import Transformer, _PendingControl
+
+
+@torch.no_grad()
+def generate(model: Transformer, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, condition=None,
+             condition_null=None, condition_token_nums=0, control_strength=1, **sampling_kwargs):
+    """Returns int32 [B, max_new_tokens] on cond.device.  sampling_kwargs: temperature, top_k, top_p, sample_logits
+    (generate.py:59).  `condition` is the control image [B,3,H,W] in [-1,1] (or None)."""
+    if model.model_type != "t2i":
+        raise Exception("please check model type")
+    eng = model.engine
+    if condition is not None:
+        if isinstance(condition, _PendingControl):
+            condition = condition.img
+        eng.encode_control(condition)                       # model.adapter + model.adapter_mlp (generate.py:136-138)
+    if emb_masks is not None:
+        assert emb_masks.shape[0] == cond.shape[0]          # generate.py:185-186
+        assert emb_masks.shape[-1] == cond.shape[1]
+    out = eng.generate(cond, int(max_new_tokens), emb_masks, cfg_scale=float(cfg_scale), cfg_interval=int(cfg_interval),
+                       use_control=condition is not None, control_strength=float(control_strength),
+                       temperature=float(sampling_kwargs.get("temperature", 1.0)), top_k=int(sampling_kwargs.get("top_k", 0) or 0),
+                       top_p=float(sampling_kwargs.get("top_p", 1.0)), sample_logits=bool(sampling_kwargs.get("sample_logits", True)),
+                       seed=int(sampling_kwargs.get("seed", 0)))
+    return out.to(cond.device)

@@ -1,0 +1,159 @@
+"""Drop-in model objects mirroring the reference factories
+(autoregressive/models/gpt_t2i.py:566-569 ``GPT_models``; tokenizer/tokenizer_image/vq_model.py:422-424
+``VQ_models``).  They keep the attributes ``generate()`` and the sampler scripts touch
+(generate.py:137-182; sample_t2i.py:43-83,163-176) but hold no torch parameters: weights live,
+packed, inside the HIP context (controlar_amd/engine.py)."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+
+from .config import GPTConfig, PathConfig, ViTConfig, VQConfig
+from .engine import Engine
+
+_SIZES = {  # reference: gpt_t2i.py:541-563
+    "GPT-B": dict(n_layer=12, n_head=12, dim=768), "GPT-L": dict(n_layer=24, n_head=16, dim=1024),
+    "GPT-XL": dict(n_layer=36, n_head=20, dim=1280), "GPT-XXL": dict(n_layer=48, n_head=24, dim=1536),
+    "GPT-1B": dict(n_layer=22, n_head=32, dim=2048), "GPT-3B": dict(n_layer=24, n_head=32, dim=3200),
+}
+
+
+class _PendingControl:
+    """What ``model.adapter(x)`` returns: the control image waiting for ``model.adapter_mlp``."""
+
+    def __init__(self, img):
+        self.img = img
+
+
+class Transformer:
+    """Stands in for gpt_t2i.Transformer on the inference path (t2i)."""
+
+    def __init__(self, gpt: GPTConfig, vit: Optional[ViTConfig] = None):
+        if gpt.model_type != "t2i":
+            raise Exception("please check model type")            # generate.py:173 wording
+        if vit is None:
+            vit = ViTConfig() if gpt.adapter_size == "small" else ViTConfig(hidden=768, heads=12)
+        self.cfg = PathConfig(gpt=gpt, vit=vit, vq=VQConfig())
+        self.config = gpt
+        self.model_type, self.num_classes = gpt.model_type, gpt.num_classes
+        self.vocab_size, self.block_size, self.cls_token_num, self.n_layer = gpt.vocab_size, gpt.block_size, gpt.cls_token_num, gpt.n_layer
+        self._dtype = torch.bfloat16
+        self._device = None
+        self._sd: Dict[str, torch.Tensor] = {}
+        self._engine: Optional[Engine] = None
+        self.tok_embeddings = SimpleNamespace(weight=SimpleNamespace(dtype=self._dtype))
+        self.cls_embedding = SimpleNamespace(uncond_embedding=None)
+        self.max_batch_size = self.max_seq_length = -1
+        self.training = False
+
+    # ---- torch.nn.Module look-alikes used by the sampler scripts
+    def load_state_dict(self, sd, strict: bool = False):
+        self._sd.update({k: v for k, v in sd.items() if torch.is_tensor(v)})
+        if "cls_embedding.uncond_embedding" in sd:
+            self.cls_embedding.uncond_embedding = sd["cls_embedding.uncond_embedding"]
+        self._engine = None
+        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+
+    def to(self, *args, **kw):
+        for a in list(args) + list(kw.values()):
+            if isinstance(a, torch.dtype):
+                self._dtype = a
+            elif isinstance(a, (str, torch.device)):
+                self._device = torch.device(a)
+        self.tok_embeddings.weight.dtype = self._dtype
+        self._engine = None
+        return self
+
+    def eval(self):
+        return self
+
+    def setup_caches(self, max_batch_size, max_seq_length, dtype):
+        """gpt_t2i.py:391-405 re-allocates KV cache + bool mask every call; here the library owns them."""
+        self.max_batch_size, self.max_seq_length = max_batch_size, max_seq_length
+
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            prec = "bf16" if self._dtype == torch.bfloat16 else "fp32"
+            self._engine = Engine(self.cfg, prec, device=self._device)
+            self._engine.load_state_dict(self._sd, finalize=True)
+        return self._engine
+
+    # generate.py:136-138 calls these two in sequence
+    def adapter(self, x):
+        return _PendingControl(x)
+
+    def adapter_mlp(self, pending):
+        return self.engine.encode_control(pending.img, want_output=True)
+
+
+def _gpt_factory(name):
+    def make(**kw):
+        kw = dict(kw)
+        known = {f for f in GPTConfig.__dataclass_fields__}
+        extra = {k: kw.pop(k) for k in list(kw) if k not in known}      # training-only ModelArgs (dropouts, ...) are accepted and ignored
+        del extra
+        return Transformer(GPTConfig(**_SIZES[name], **kw))
+    return make
+
+
+GPT_models = {k: _gpt_factory(k) for k in _SIZES}
+
+
+class VQModel:
+    """Stands in for vq_model.VQModel on the decode side (decode_code only; the encoder is training-time)."""
+
+    def __init__(self, vq: VQConfig):
+        self.vq = vq
+        self.config = vq
+        self._dtype = torch.float32            # the reference never casts the VQ model (sample_t2i.py:43-47)
+        self._device = None
+        self._sd: Dict[str, torch.Tensor] = {}
+        self._engine: Optional[Engine] = None
+
+    def load_state_dict(self, sd, strict: bool = False):
+        self._sd.update({k: v for k, v in sd.items() if torch.is_tensor(v)})
+        self._engine = None
+        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+
+    def to(self, *args, **kw):
+        for a in list(args) + list(kw.values()):
+            if isinstance(a, torch.dtype):
+                self._dtype = a
+            elif isinstance(a, (str, torch.device)):
+                self._device = torch.device(a)
+        self._engine = None
+        return self
+
+    def eval(self):
+        return self
+
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            from .config import tiny_t2i
+            cfg = tiny_t2i()                   # GPT/ViT halves of the context stay empty
+            cfg.vq = self.vq
+            self._engine = Engine(cfg, "bf16" if self._dtype == torch.bfloat16 else "fp32", device=self._device)
+            self._engine.load_state_dict(self._sd, finalize=True)
+        return self._engine
+
+    def decode_code(self, code_b, shape=None, channel_first=True):
+        """vq_model.py:53-56: code_b [B, h*w] (or flat), shape [B, C, h, w] -> fp32 [B,3,16h,16w]."""
+        if shape is None or not channel_first:
+            raise NotImplementedError("decode_code needs shape=[B,C,h,w], channel_first=True (the only form on the path)")
+        B, _, h, w = shape
+        return self.engine.vq_decode(code_b.reshape(B, h * w), h, w)
+
+
+def VQ_16(**kw):
+    return VQModel(VQConfig(ch_mult=(1, 1, 2, 2, 4), **kw))
+
+
+def VQ_8(**kw):
+    return VQModel(VQConfig(ch_mult=(1, 2, 2, 4), **kw))
+
+
+VQ_models = {"VQ-16": VQ_16, "VQ-8": VQ_8}

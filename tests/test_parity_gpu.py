@@ -156,3 +156,24 @@ def test_two_chain_decode_large_batch():
     t2 = eng.generate(emb2.cuda(), n_new, mask2.cuda(), cfg_scale=1.0).cpu()
     assert torch.equal(t2[:16], t2[16:])
     eng.close()
+
+
+def test_dropin_api_matches_reference_signatures():
+    """controlar_amd.generate.generate / GPT_models / VQ_models used exactly like sample_t2i.py:43-83,163-176."""
+    from controlar_amd.generate import generate
+    from controlar_amd.models import Transformer, VQModel
+    cs = load_case("tiny_depth_cfg4"); gold = cs["gold"]; cfg = cs["cfg"]
+    gpt = Transformer(cfg.gpt, cfg.vit).to("cuda", dtype=torch.float32)
+    gpt.load_state_dict(cs["gsd"], strict=False); gpt.eval()
+    vq = VQModel(cfg.vq); vq.to("cuda"); vq.eval(); vq.load_state_dict(cs["vsd"])
+    toks = generate(gpt, cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"],
+                    temperature=1.0, top_k=0, top_p=1.0, sample_logits=False, control_strength=cs["control_strength"])
+    assert toks.dtype == torch.int32 and tuple(toks.shape) == (cs["B"], cs["n_new"])
+    assert np.array_equal(toks.cpu().numpy(), gold["tokens"])
+    px = vq.decode_code(toks, [cs["B"], cfg.vq.codebook_embed_dim, cs["H"] // 16, cs["W"] // 16])
+    np.testing.assert_allclose(px.cpu().numpy(), gold["pixels"], atol=5e-4, rtol=1e-4)
+    with pytest.raises(RuntimeError):          # stochastic sampling is not built yet: loud, no fallback
+        generate(gpt, cs["emb"].cuda(), 4, cs["mask"].cuda(), condition=cs["img"].cuda(), sample_logits=True)
+    # no control image at all (condition=None) is a legal call of the reference too
+    t0 = generate(gpt, cs["emb"].cuda(), 8, cs["mask"].cuda(), condition=None, cfg_scale=1.0, sample_logits=False)
+    assert tuple(t0.shape) == (cs["B"], 8)

@@ -8,12 +8,15 @@ from controlar_amd.engine import Engine
 model = sys.argv[1] if len(sys.argv) > 1 else "xl"
 batches = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "2,8,16,32,64").split(",")]
 n_new = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+chains = [x for x in (sys.argv[4] if len(sys.argv) > 4 else "").split(",") if x] or [None]
 cfg = C.xl_t2i(1024) if model == "xl" else C.b_t2i(1024)
 t0 = time.time()
 gsd, _ = synth.path_state_dicts(cfg, 0)
 eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
 print("load %.1fs" % (time.time() - t0), flush=True)
-for B in batches:
+for B, ch in [(B, ch) for B in batches for ch in chains]:
+    if ch is not None:
+        os.environ["CAR_CHAINS"] = ch
     img = synth.canny_like_control(B, 512, 512).to(torch.bfloat16).cuda()
     emb, mask = synth.text_embeddings(B, 120, 2048)
     emb = emb.to(torch.bfloat16).cuda(); mask = mask.cuda()
@@ -24,5 +27,5 @@ for B in batches:
         st = eng.stats()
     ms = st["decode_ms"] / st["decode_steps"]
     gbs = st["decode_algo_bytes"] / st["decode_steps"] / (ms * 1e-3) / 1e9
-    print(json.dumps(dict(B=B, n_new=n_new, enc_ms=(t1 - t0) * 1e3, gen_ms=(t2 - t1) * 1e3, prefill_ms=st["prefill_ms"], ms_per_step=ms,
+    print(json.dumps(dict(B=B, chains=ch, n_new=n_new, enc_ms=(t1 - t0) * 1e3, gen_ms=(t2 - t1) * 1e3, prefill_ms=st["prefill_ms"], ms_per_step=ms,
                           algo_GBps=gbs, frac=gbs / 8000, kernels=st["decode_kernels_per_step"])), flush=True)
