@@ -31,8 +31,9 @@ template <typename T>
 __device__ inline void load16(const T* p, float (&v)[VecT<T>::EPL]);
 template <>
 __device__ inline void load16<bf16_t>(const bf16_t* p, float (&v)[8]) {
-    const uint4 u = *(const uint4*)p;
-    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    // KV rows are read once per step and the cache (tens of GB) never fits on chip: non-temporal, keep L2/MALL for weights
+    const u32x4 u = __builtin_nontemporal_load((const u32x4*)p);
+    const unsigned w[4] = {u[0], u[1], u[2], u[3]};
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }

@@ -916,7 +916,8 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval * 4 + NG, (const void*)forced_tokens, (void*)logits_out);
         const std::string key(keyb);
         bool graph_ok = true;
-        if (!c->gexec || c->gkey != key) {
+        if (getenv("CAR_NO_GRAPH")) { /* skip capture */ }
+        else if (!c->gexec || c->gkey != key) {
             if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_ok = false; (void)hipGetLastError(); }
@@ -928,6 +929,7 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
             if (graph) (void)hipGraphDestroy(graph);
             if (graph_ok) c->gkey = key;
         }
+        if (getenv("CAR_NO_GRAPH")) graph_ok = false;      // profiling aid: eager launches (PMC collection cannot follow graph replays)
         if (graph_ok) {
             for (int i = 0; i < nsteps; ++i) HIPCHK(c, hipGraphLaunch(c->gexec, st));
             c->stats.graph_used = 1;

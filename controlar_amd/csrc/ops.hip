@@ -282,19 +282,23 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const void* x_, float* 
     float* o = part + ((long)b * nchunk + chunk) * 2 * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) { o[c] = accS[c]; o[C + c] = accQ[c]; }
 }
-__global__ void gn_finalize_kernel(const float* part, float* stats, int nchunk, int C, int G, int HW, float eps) {
-    const int b = blockIdx.x, g = threadIdx.x;
-    if (g >= G) return;
+// one wave per (b, group): lanes stride over (chunk, channel-in-group) pairs, double accumulation, fixed-order wave reduce
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* part, float* stats, int nchunk, int C, int G, int HW, float eps) {
+    const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
     const int cpg = C / G;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
+    for (int i = lane; i < nchunk * cpg; i += 64) {
+        const int k = i / cpg, c = g * cpg + (i - k * cpg);
         const float* o = part + ((long)b * nchunk + k) * 2 * C;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += o[c]; q += o[C + c]; }
+        s += o[c]; q += o[C + c];
     }
-    const double n = (double)HW * cpg, mean = s / n;
-    double var = q / n - mean * mean; if (var < 0) var = 0;
-    stats[((long)b * G + g) * 2] = (float)mean;
-    stats[((long)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+    if (lane == 0) {
+        const double n = (double)HW * cpg, mean = s / n;
+        double var = q / n - mean * mean; if (var < 0) var = 0;
+        stats[((long)b * G + g) * 2] = (float)mean;
+        stats[((long)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 template <typename T>
 __global__ void gn_apply_kernel(const void* x_, const float* stats, const void* gamma_, const void* beta_, void* y_, int B, int HW, int C, int G, int swish) {
@@ -317,7 +321,7 @@ extern "C" void car_launch_groupnorm(int mode, const void* x, const void* gamma,
     const size_t shb = (2 * C + 512) * sizeof(float);
     if (mode == 1) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
     else hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, st, part, stats, nchunk, C, G, HW, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, st, part, stats, nchunk, C, G, HW, eps);
     long total = (long)B * HW * C; int g = (int)((total + 255) / 256); if (g > 8192) g = 8192;
     LAUNCH_T(mode, gn_apply_kernel, dim3(g), dim3(256), st, x, stats, gamma, beta, y, B, HW, C, G, swish);
 }
@@ -348,22 +352,37 @@ extern "C" void car_launch_vq_lookup(int mode, const int* tok, const float* cb, 
 
 // ------------------------------------------------------------------ conv_out 3x3 C->3 on NHWC input, fp32 NCHW output (vq_model.py:168,194)
 // weights packed [3][9][C]; one lane per output pixel, channels in the inner loop.
+template <typename T> struct LdVec;
+template <> struct LdVec<bf16_t> { static constexpr int N = 8;
+    __device__ static inline void ld(const bf16_t* p, float (&v)[8]) {
+        const uint4 u = *(const uint4*)p; const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); } } };
+template <> struct LdVec<float> { static constexpr int N = 4;
+    __device__ static inline void ld(const float* p, float (&v)[4]) { const float4 u = *(const float4*)p; v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; } };
+
+// one lane per output pixel; the 27*C weights sit in LDS as fp32 (wave-uniform reads broadcast); 16-byte activation loads
 template <typename T>
 __global__ __launch_bounds__(256) void conv_out_kernel(const void* x_, const void* w_, const float* bias, float* out, int B, int H, int W, int C) {
+    extern __shared__ float wsm[];       // [3][9][C]
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) wsm[i] = ET<T>::ld((const T*)w_ + i);
+    __syncthreads();
     const long npix = (long)B * H * W;
     const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= npix) return;
     const int x = (int)(pix % W), y = (int)((pix / W) % H); const long b = pix / ((long)W * H);
-    const T* X = (const T*)x_; const T* Wt = (const T*)w_;
+    const T* X = (const T*)x_;
+    constexpr int VN = LdVec<T>::N;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int tap = 0; tap < 9; ++tap) {
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
         const T* px = X + ((b * H + yy) * W + xx) * C;
-        const T* w0 = Wt + (0 * 9 + tap) * C; const T* w1 = Wt + (1 * 9 + tap) * C; const T* w2 = Wt + (2 * 9 + tap) * C;
-        for (int c = 0; c < C; ++c) {
-            const float v = ET<T>::ld(px + c);
-            a0 = fmaf(v, ET<T>::ld(w0 + c), a0); a1 = fmaf(v, ET<T>::ld(w1 + c), a1); a2 = fmaf(v, ET<T>::ld(w2 + c), a2);
+        const float* w0 = wsm + (0 * 9 + tap) * C; const float* w1 = wsm + (1 * 9 + tap) * C; const float* w2 = wsm + (2 * 9 + tap) * C;
+        for (int c = 0; c < C; c += VN) {
+            float v[VN]; LdVec<T>::ld(px + c, v);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) { a0 = fmaf(v[e], w0[c + e], a0); a1 = fmaf(v[e], w1[c + e], a1); a2 = fmaf(v[e], w2[c + e], a2); }
         }
     }
     const long hw = (long)H * W, o = b * 3 * hw + (long)y * W + x;
@@ -371,7 +390,9 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const void* x_, const voi
 }
 extern "C" void car_launch_conv_out(int mode, const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int C, hipStream_t st) {
     const long npix = (long)B * H * W;
-    LAUNCH_T(mode, conv_out_kernel, dim3((npix + 255) / 256), dim3(256), st, x, w, bias, out, B, H, W, C);
+    const size_t shb = (size_t)27 * C * sizeof(float);
+    if (mode == 1) hipLaunchKernelGGL(conv_out_kernel<bf16_t>, dim3((npix + 255) / 256), dim3(256), shb, st, x, w, bias, out, B, H, W, C);
+    else hipLaunchKernelGGL(conv_out_kernel<float>, dim3((npix + 255) / 256), dim3(256), shb, st, x, w, bias, out, B, H, W, C);
 }
 
 // ------------------------------------------------------------------ exact-mode SwiGLU on the block-16 interleaved w1|w3 layout

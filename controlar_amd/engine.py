@@ -31,7 +31,10 @@ class Engine:
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("controlar_amd needs a HIP device (no CPU fallback)")
-        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        dev = torch.device(device if device is not None else "cuda")
+        if dev.type != "cuda":
+            raise RuntimeError(f"controlar_amd runs on a HIP device only, got {dev}")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         torch.cuda.set_device(self.device)
         self.cfg = cfg
         self.precision = precision
