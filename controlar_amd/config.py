@@ -60,7 +60,7 @@ class GPTConfig:
 
 @dataclass
 class ViTConfig:
-    """DINOv2 encoder as the reference instantiates it."""
+    """Control encoder as the reference instantiates it: DINOv2-S/B (t2i) or ViT-S/16 (c2i)."""
     hidden: int = 384
     layers: int = 12
     heads: int = 6
@@ -68,6 +68,7 @@ class ViTConfig:
     patch: int = 14
     image_size: int = 518             # native pos-emb grid = image_size // patch = 37
     ln_eps: float = 1e-6
+    variant: str = "dinov2"           # "dinov2" (LayerScale, resize to patch-14 grid) | "vit" (HF ViTModel, no LayerScale, no resize)
 
     @property
     def mlp(self) -> int:
@@ -113,6 +114,26 @@ def b_t2i(block_size: int = 256, adapter_size: str = "small", condition_type: st
     return PathConfig(gpt=GPTConfig(dim=768, n_layer=12, n_head=12, block_size=block_size,
                                     adapter_size=adapter_size, condition_type=condition_type),
                       vit=vit, vq=VQConfig())
+
+
+def vit_small16() -> ViTConfig:
+    """WinKawaks/vit-small-patch16-224 as gpt.py:319 / vit_adapter.py:11 load it."""
+    return ViTConfig(hidden=384, layers=12, heads=6, mlp_ratio=4, patch=16, image_size=224, ln_eps=1e-12, variant="vit")
+
+
+def b_c2i(block_size: int = 256) -> PathConfig:
+    """BASELINE config 1: LlamaGen-B class-conditional + ViT-S/16 control (reference gpt.py:542, sample_c2i.py:49-57)."""
+    return PathConfig(gpt=GPTConfig(dim=768, n_layer=12, n_head=12, block_size=block_size, cls_token_num=1, model_type="c2i",
+                                    condition_type="canny"), vit=vit_small16(), vq=VQConfig())
+
+
+def tiny_c2i(block_size: int = 64, vocab_size: int = 1024, num_classes: int = 10) -> PathConfig:
+    return PathConfig(
+        gpt=GPTConfig(dim=256, n_layer=6, n_head=4, vocab_size=vocab_size, block_size=block_size, cls_token_num=1,
+                      model_type="c2i", num_classes=num_classes, condition_type="canny"),
+        vit=ViTConfig(hidden=128, layers=3, heads=2, mlp_ratio=4, patch=16, image_size=224, ln_eps=1e-12, variant="vit"),
+        vq=VQConfig(codebook_size=vocab_size, z_channels=64, ch=32),
+    )
 
 
 def tiny_t2i(block_size: int = 64, condition_type: str = "canny", vocab_size: int = 1024) -> PathConfig:

@@ -60,6 +60,7 @@ void car_launch_advance(int* pos, int* step, hipStream_t st);
 void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st);
 void car_launch_dec_attn(int mode, const AttnP* p, int b, hipStream_t st);
 void car_launch_dec_linear(const LinP* p, hipStream_t st);
+void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st);
 void car_launch_swiglu_parts(const float* parts, int ks, long stride, void* out, int rows, int hidden, hipStream_t st);
 void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, hipStream_t st);
 }
@@ -237,10 +238,31 @@ static int upload_packed(car_ctx* c, const std::string& name, const std::vector<
     return 0;
 }
 
+static void replace_all(std::string& s, const std::string& a, const std::string& b) {
+    size_t p = 0; while ((p = s.find(a, p)) != std::string::npos) { s.replace(p, a.size(), b); p += b.size(); }
+}
+// HF ViTModel key names (transformers 5.x "layers.N.attention.q_proj", and the 4.x checkpoint names
+// "encoder.layer.N.attention.attention.query / intermediate.dense / output.dense") -> the encoder's canonical names
+static std::string canon_name(const std::string& in) {
+    if (in.compare(0, 14, "adapter.model.") != 0) return in;
+    std::string s = in;
+    replace_all(s, "adapter.model.layers.", "adapter.model.encoder.layer.");
+    replace_all(s, ".attention.q_proj.", ".attention.attention.query.");
+    replace_all(s, ".attention.k_proj.", ".attention.attention.key.");
+    replace_all(s, ".attention.v_proj.", ".attention.attention.value.");
+    replace_all(s, ".attention.o_proj.", ".attention.output.dense.");
+    replace_all(s, ".layernorm_before.", ".norm1.");
+    replace_all(s, ".layernorm_after.", ".norm2.");
+    replace_all(s, ".intermediate.dense.", ".mlp.fc1.");
+    if (s.find(".attention.output.dense.") == std::string::npos) replace_all(s, ".output.dense.", ".mlp.fc2.");
+    return s;
+}
+
 extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, const int64_t* shape, int32_t ndim, int32_t dtype) {
     if (!c || !cname || !ptr || (ndim > 0 && !shape)) { if (c) c->err = "car_load_tensor: null argument"; return -1; }
     if (dtype != CAR_DT_F32 && dtype != CAR_DT_BF16) FAIL(c, "car_load_tensor(%s): dtype must be F32 or BF16", cname);
-    const std::string name(cname);
+    const std::string name = canon_name(cname);
+    if (name.find("adapter.model.pooler.") == 0 || name == "condition_norm.weight") return 0;   // present in c2i checkpoints, unused on the path
     // reference tensors that the inference path never reads
     if (name == "condition_embeddings.weight" || name == "condition_mlp.uncond_embedding" || ends_with(name, "mask_token") ||
         starts_with(name, "encoder.") || starts_with(name, "quant_conv.") || name == "quantize.codebook_used") return 0;
@@ -346,9 +368,10 @@ extern "C" int car_finalize_weights(car_ctx* c) {
     if (!c) return -1;
     const car_config& g = c->cfg;
     std::vector<std::string> req = {
-        "tok_embeddings.weight", "cls_embedding.cap_proj.fc1.weight", "cls_embedding.cap_proj.fc2.weight", "cls_embedding.uncond_embedding",
-        "adapter_mlp.fc1.weight", "adapter_mlp.fc2.weight", "condition_mlp.cap_proj.fc1.weight", "condition_mlp.cap_proj.fc2.weight",
+        "tok_embeddings.weight", "adapter_mlp.fc1.weight", "adapter_mlp.fc2.weight", "condition_mlp.cap_proj.fc1.weight", "condition_mlp.cap_proj.fc2.weight",
         "norm.weight", "output.weight" };
+    if (g.model_type == 1) req.push_back("cls_embedding.embedding_table.weight");
+    else for (const char* s : {"cls_embedding.cap_proj.fc1.weight", "cls_embedding.cap_proj.fc2.weight", "cls_embedding.uncond_embedding"}) req.push_back(s);
     for (int k = 0; k < 3; ++k) { req.push_back("condition_layers." + std::to_string(k) + ".fc1.weight"); req.push_back("condition_layers." + std::to_string(k) + ".fc2.weight"); }
     for (int i = 0; i < g.n_layer; ++i) {
         const std::string p = "layers." + std::to_string(i) + ".";
@@ -360,8 +383,9 @@ extern "C" int car_finalize_weights(car_ctx* c) {
         const std::string p = a + "encoder.layer." + std::to_string(i) + ".";
         for (const char* s : {"norm1.weight", "norm1.bias", "attention.attention.query.weight", "attention.attention.query.bias", "attention.attention.key.weight",
                               "attention.attention.key.bias", "attention.attention.value.weight", "attention.attention.value.bias", "attention.output.dense.weight",
-                              "attention.output.dense.bias", "layer_scale1.lambda1", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
-                              "mlp.fc2.bias", "layer_scale2.lambda1"}) req.push_back(p + s);
+                              "attention.output.dense.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
+                              "mlp.fc2.bias"}) req.push_back(p + s);
+        if (g.vit_variant == 0) { req.push_back(p + "layer_scale1.lambda1"); req.push_back(p + "layer_scale2.lambda1"); }
     }
     std::string missing;
     int nmiss = 0;
@@ -562,7 +586,7 @@ extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype
             }
             {   // h = layer_scale1(dense(ctx)) + h   (HF :342-363)
                 GemmP q = gp(ctx, D, Wp(c, L + "attention.output.dense.weight"), D, h, D, (int)rows, D, D);
-                q.bias = Wp(c, L + "attention.output.dense.bias"); q.bias_mode = BIAS_N; q.scale = Wp(c, L + "layer_scale1.lambda1"); q.R = h; q.ldr = D;
+                q.bias = Wp(c, L + "attention.output.dense.bias"); q.bias_mode = BIAS_N; q.scale = g.vit_variant == 0 ? Wp(c, L + "layer_scale1.lambda1") : nullptr; q.R = h; q.ldr = D;
                 car_launch_gemm(mode, AMODE_PLAIN, &q, st);
             }
             car_launch_layernorm(mode, h, Wp(c, L + "norm2.weight"), Wp(c, L + "norm2.bias"), y, rows, D, g.vit_ln_eps, st);
@@ -571,7 +595,7 @@ extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype
                 q.bias = Wp(c, L + "mlp.fc1.bias"); q.bias_mode = BIAS_N; q.act = ACT_GELU_ERF;
                 car_launch_gemm(mode, AMODE_PLAIN, &q, st);
                 GemmP r = gp(mid, g.vit_mlp, Wp(c, L + "mlp.fc2.weight"), g.vit_mlp, h, D, (int)rows, D, g.vit_mlp);
-                r.bias = Wp(c, L + "mlp.fc2.bias"); r.bias_mode = BIAS_N; r.scale = Wp(c, L + "layer_scale2.lambda1"); r.R = h; r.ldr = D;
+                r.bias = Wp(c, L + "mlp.fc2.bias"); r.bias_mode = BIAS_N; r.scale = g.vit_variant == 0 ? Wp(c, L + "layer_scale2.lambda1") : nullptr; r.R = h; r.ldr = D;
                 car_launch_gemm(mode, AMODE_PLAIN, &r, st);
             }
         }
@@ -718,15 +742,36 @@ static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b, int B, int
 }
 
 // ------------------------------------------------------------------------------------- generate
+static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, const int64_t* labels, const int64_t* emb_mask, int32_t B, int32_t n_new,
+                         int32_t use_control, const car_sampling* sp, int32_t* out_tokens, const int32_t* forced_tokens,
+                         float* logits_out, void* stream_);
+
 extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype, const int64_t* emb_mask, int32_t B, int32_t n_new,
                             int32_t use_control, const car_sampling* sp, int32_t* out_tokens, const int32_t* forced_tokens,
                             float* logits_out, void* stream_) {
     if (!c) return -1;
+    if (c->cfg.model_type != 0) FAIL(c, "car_generate: context was created for the c2i model; use car_generate_c2i");
+    if (!text_emb) FAIL(c, "car_generate: bad arguments");
+    if (text_dtype != CAR_DT_F32 && text_dtype != CAR_DT_BF16) FAIL(c, "car_generate: text dtype must be F32 or BF16");
+    return generate_impl(c, text_emb, text_dtype, nullptr, emb_mask, B, n_new, use_control, sp, out_tokens, forced_tokens, logits_out, stream_);
+}
+
+extern "C" int car_generate_c2i(car_ctx* c, const int64_t* labels, int32_t B, int32_t n_new, int32_t use_control, const car_sampling* sp,
+                                int32_t* out_tokens, const int32_t* forced_tokens, float* logits_out, void* stream_) {
+    if (!c) return -1;
+    if (c->cfg.model_type != 1) FAIL(c, "car_generate_c2i: context was created for the t2i model; use car_generate");
+    if (!labels) FAIL(c, "car_generate_c2i: bad arguments");
+    return generate_impl(c, nullptr, CAR_DT_F32, labels, nullptr, B, n_new, use_control, sp, out_tokens, forced_tokens, logits_out, stream_);
+}
+
+static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, const int64_t* labels, const int64_t* emb_mask, int32_t B, int32_t n_new,
+                         int32_t use_control, const car_sampling* sp, int32_t* out_tokens, const int32_t* forced_tokens,
+                         float* logits_out, void* stream_) {
     if (!c->finalized) FAIL(c, "car_generate: call car_finalize_weights first");
     if (!c->has_gpt) FAIL(c, "car_generate: this context holds VQ weights only");
-    if (!text_emb || !sp || !out_tokens || B <= 0 || n_new <= 0) FAIL(c, "car_generate: bad arguments");
-    if (text_dtype != CAR_DT_F32 && text_dtype != CAR_DT_BF16) FAIL(c, "car_generate: text dtype must be F32 or BF16");
+    if (!sp || !out_tokens || B <= 0 || n_new <= 0) FAIL(c, "car_generate: bad arguments");
     const car_config& g = c->cfg;
+    const bool c2i = g.model_type == 1;
     if (sp->sample_logits) FAIL(c, "car_generate: stochastic sampling (sample_logits=True) is not built yet; greedy only");
     if (sp->top_p < 1.0f) { /* greedy: filtering never changes the arg-max */ }
     const int T = g.cls_token_num;
@@ -734,7 +779,7 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
     if (use_control && (c->ctrl_B != B || c->ctrl_ntok < n_new)) FAIL(c, "car_generate: control tokens cached for B=%d n=%d, requested B=%d n_new=%d", c->ctrl_B, c->ctrl_ntok, B, n_new);
     const bool use_cfg = sp->cfg_scale > 1.0f;
     const int b = use_cfg ? 2 * B : B;
-    const float cs = use_cfg ? sp->control_strength : 1.0f;         // generate.py:87-92: strength ignored when cfg <= 1
+    const float cs = (use_cfg && !c2i) ? sp->control_strength : 1.0f;   // generate.py:87-92: strength ignored when cfg <= 1; absent in gpt.py
     const int S_max = (int)rup(T + n_new, 8);                       // gpt_t2i.py:395
     const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, V = g.vocab_size, n_tok = c->ctrl_ntok, li = g.n_layer / 3;
     const int mode = c->mode; const size_t e = c->esz;
@@ -791,8 +836,25 @@ extern "C" int car_generate(car_ctx* c, const void* text_emb, int32_t text_dtype
     // ---- D. text prefix embed: cls_embedding.cap_proj (gpt_t2i.py:435), uncond rows = uncond_embedding (generate.py:157)
     void *text = c->ws[0].p, *h = c->ws[1].p, *xn = c->ws[2].p, *qkv = c->ws[3].p, *P = c->ws[5].p, *vT = c->ws[6].p, *mid = c->ws[7].p, *att = c->ws[8].p;
     float* S = (float*)c->ws[4].p; float* logits = (float*)c->ws[9].p;
-    car_launch_build_text(mode, text_emb, text_dtype, Wp(c, "cls_embedding.uncond_embedding"), text, B, (long)T * g.caption_dim, use_cfg, st);
-    mlp_tanh(c, text, g.caption_dim, 0, 1, (int)rowsP, g.caption_dim, "cls_embedding.cap_proj.", xn, h, D, st);
+    if (c2i) {
+        // LabelEmbedder (gpt.py:89-96): h[b] = embedding_table[label]; CFG rows use the null class num_classes (generate.py:141)
+        std::vector<int64_t> hl((size_t)B);
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipMemcpy(hl.data(), labels, (size_t)B * 8, hipMemcpyDeviceToHost));
+        std::vector<int> idx((size_t)b);
+        for (int i = 0; i < b; ++i) {
+            const int64_t l = i < B ? hl[(size_t)i] : (int64_t)g.num_classes;
+            if (l < 0 || l > g.num_classes) FAIL(c, "car_generate_c2i: class label %lld out of range [0,%d]", (long long)l, g.num_classes);
+            idx[(size_t)i] = (int)l;
+        }
+        int* didx = cur;       // cur_tok[b] is free until the prefill sampler writes it
+        HIPCHK(c, hipMemcpyAsync(didx, idx.data(), (size_t)b * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        car_launch_gather_rows(mode, Wp(c, "cls_embedding.embedding_table.weight"), didx, h, b, D, st);
+    } else {
+        car_launch_build_text(mode, text_emb, text_dtype, Wp(c, "cls_embedding.uncond_embedding"), text, B, (long)T * g.caption_dim, use_cfg, st);
+        mlp_tanh(c, text, g.caption_dim, 0, 1, (int)rowsP, g.caption_dim, "cls_embedding.cap_proj.", xn, h, D, st);
+    }
     // ---- C. control tokens: condition_mlp then 3 condition_layers, cached for the whole call (gpt_t2i.py:437-442)
     if (use_control) {
         const int Mc = B * n_tok;

@@ -45,6 +45,18 @@ extern "C" void car_launch_build_text(int mode, const void* cond, int src_dtype,
     LAUNCH_T(mode, build_text_kernel, dim3(2048), dim3(256), st, cond, src_dtype, uncond, dst, B, per, use_cfg);
 }
 
+// out[r, :] = table[idx[r], :]   (LabelEmbedder / tok_embeddings gather)
+template <typename T>
+__global__ void gather_rows_kernel(const void* table, const int* idx, void* out, long rows, int D) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x, n = rows * D;
+    for (; i < n; i += stride) { const long r = i / D; const int d = (int)(i - r * D); ((T*)out)[i] = ((const T*)table)[(long)idx[r] * D + d]; }
+}
+extern "C" void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st) {
+    long n = rows * D; int g = (int)((n + 255) / 256); if (g > 2048) g = 2048;
+    LAUNCH_T(mode, gather_rows_kernel, dim3(g), dim3(256), st, table, idx, out, rows, D);
+}
+
 // ------------------------------------------------------------------ LayerNorm (HF Dinov2Layer norm1/norm2/layernorm, eps 1e-6)
 template <typename T>
 __global__ __launch_bounds__(128) void layernorm_kernel(const void* x_, const void* w_, const void* b_, void* y_, int D, float eps) {

@@ -48,8 +48,13 @@ class Engine:
         cc.norm_eps, cc.rope_base = g.norm_eps, g.rope_base
         cc.vit_hidden, cc.vit_layers, cc.vit_heads, cc.vit_mlp = v.hidden, v.layers, v.heads, v.mlp
         cc.vit_patch, cc.vit_pos_grid, cc.vit_ln_eps = v.patch, v.pos_grid, v.ln_eps
-        # dinov2_adapter.py:19-23: nearest for canny/seg, bicubic(align_corners=True) otherwise
-        cc.resize_mode = L.CAR_RESIZE_NEAREST if g.condition_type in ("canny", "seg") else L.CAR_RESIZE_BICUBIC_AC
+        # dinov2_adapter.py:19-23: nearest for canny/seg, bicubic(align_corners=True) otherwise; the c2i ViT adapter
+        # (vit_adapter.py:13-15) does not resize: nearest onto the same grid is the identity
+        vit16 = getattr(v, "variant", "dinov2") == "vit"
+        cc.resize_mode = L.CAR_RESIZE_NEAREST if (vit16 or g.condition_type in ("canny", "seg")) else L.CAR_RESIZE_BICUBIC_AC
+        cc.vit_variant = 1 if vit16 else 0
+        cc.model_type = 1 if g.model_type == "c2i" else 0
+        cc.num_classes = g.num_classes
         cc.codebook_size, cc.codebook_dim, cc.z_channels, cc.vq_ch = q.codebook_size, q.codebook_embed_dim, q.z_channels, q.ch
         cc.vq_num_res_blocks, cc.vq_n_mult, cc.gn_eps = q.num_res_blocks, len(q.ch_mult), q.gn_eps
         for i, m in enumerate(q.ch_mult):
@@ -117,12 +122,17 @@ class Engine:
                  cfg_scale: float = 1.0, cfg_interval: int = -1, use_control: bool = True, control_strength: float = 1.0,
                  temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, sample_logits: bool = False, seed: int = 0,
                  forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
+        c2i = self.cfg.gpt.model_type == "c2i"
         cond = cond.to(self.device)
-        if cond.dtype not in (torch.float32, torch.bfloat16):
-            cond = cond.float()
-        cond = cond.contiguous()
-        B, T, cap = cond.shape
-        assert T == self.cfg.gpt.cls_token_num and cap == self.cfg.gpt.caption_dim
+        if c2i:
+            cond = cond.to(torch.int64).contiguous().view(-1)          # class labels [B]
+            B, T = cond.shape[0], 1
+        else:
+            if cond.dtype not in (torch.float32, torch.bfloat16):
+                cond = cond.float()
+            cond = cond.contiguous()
+            B, T, cap = cond.shape
+            assert T == self.cfg.gpt.cls_token_num and cap == self.cfg.gpt.caption_dim
         mask_t = None
         if emb_masks is not None:
             assert emb_masks.shape[0] == B and emb_masks.shape[-1] == T          # generate.py:185-186
@@ -135,12 +145,19 @@ class Engine:
         if forced_tokens is not None:
             forced = forced_tokens.to(device=self.device, dtype=torch.int32).contiguous()
         logits = torch.empty(B, max_new_tokens, self.cfg.gpt.vocab_size, dtype=torch.float32, device=self.device) if return_logits else None
-        self._check(self.lib.car_generate(self._h, C.c_void_p(cond.data_ptr()), _dt(cond),
-                                          C.c_void_p(mask_t.data_ptr() if mask_t is not None else 0), B, int(max_new_tokens),
-                                          int(bool(use_control)), C.byref(sp), C.c_void_p(out.data_ptr()),
-                                          C.c_void_p(forced.data_ptr() if forced is not None else 0),
-                                          C.c_void_p(logits.data_ptr() if logits is not None else 0), C.c_void_p(_stream_ptr())),
-                    "car_generate")
+        if c2i:
+            self._check(self.lib.car_generate_c2i(self._h, C.c_void_p(cond.data_ptr()), B, int(max_new_tokens), int(bool(use_control)),
+                                                  C.byref(sp), C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(forced.data_ptr() if forced is not None else 0),
+                                                  C.c_void_p(logits.data_ptr() if logits is not None else 0), C.c_void_p(_stream_ptr())),
+                        "car_generate_c2i")
+        else:
+            self._check(self.lib.car_generate(self._h, C.c_void_p(cond.data_ptr()), _dt(cond),
+                                              C.c_void_p(mask_t.data_ptr() if mask_t is not None else 0), B, int(max_new_tokens),
+                                              int(bool(use_control)), C.byref(sp), C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(forced.data_ptr() if forced is not None else 0),
+                                              C.c_void_p(logits.data_ptr() if logits is not None else 0), C.c_void_p(_stream_ptr())),
+                        "car_generate")
         return (out, logits) if return_logits else out
 
     def vq_decode(self, tokens: torch.Tensor, h: int, w: int) -> torch.Tensor:

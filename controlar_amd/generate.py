@@ -13,7 +13,7 @@ def generate(model: Transformer, cond, max_new_tokens, emb_masks=None, cfg_scale
              condition_null=None, condition_token_nums=0, control_strength=1, **sampling_kwargs):
     """Returns int32 [B, max_new_tokens] on cond.device.  sampling_kwargs: temperature, top_k, top_p, sample_logits
     (generate.py:59).  `condition` is the control image [B,3,H,W] in [-1,1] (or None)."""
-    if model.model_type != "t2i":
+    if model.model_type not in ("t2i", "c2i"):
         raise Exception("please check model type")
     eng = model.engine
     if condition is not None:
@@ -22,7 +22,9 @@ def generate(model: Transformer, cond, max_new_tokens, emb_masks=None, cfg_scale
         eng.encode_control(condition)                       # model.adapter + model.adapter_mlp (generate.py:136-138)
     if emb_masks is not None:
         assert emb_masks.shape[0] == cond.shape[0]          # generate.py:185-186
-        assert emb_masks.shape[-1] == cond.shape[1]
+        assert emb_masks.shape[-1] == (1 + condition_token_nums if model.model_type == "c2i" else cond.shape[1])
+    if model.model_type == "c2i" and condition_token_nums != 0:
+        raise RuntimeError("c2i: condition_token_nums must be 0 (the only value the reference samplers pass, sample_c2i.py:55)")
     out = eng.generate(cond, int(max_new_tokens), emb_masks, cfg_scale=float(cfg_scale), cfg_interval=int(cfg_interval),
                        use_control=condition is not None, control_strength=float(control_strength),
                        temperature=float(sampling_kwargs.get("temperature", 1.0)), top_k=int(sampling_kwargs.get("top_k", 0) or 0),

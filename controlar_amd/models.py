@@ -31,10 +31,14 @@ class Transformer:
     """Stands in for gpt_t2i.Transformer on the inference path (t2i)."""
 
     def __init__(self, gpt: GPTConfig, vit: Optional[ViTConfig] = None):
-        if gpt.model_type != "t2i":
+        if gpt.model_type not in ("t2i", "c2i"):
             raise Exception("please check model type")            # generate.py:173 wording
         if vit is None:
-            vit = ViTConfig() if gpt.adapter_size == "small" else ViTConfig(hidden=768, heads=12)
+            if gpt.model_type == "c2i":                            # gpt.py:319: ViT_Adapter() = HF ViT-S/16
+                from .config import vit_small16
+                vit = vit_small16()
+            else:
+                vit = ViTConfig() if gpt.adapter_size == "small" else ViTConfig(hidden=768, heads=12)
         self.cfg = PathConfig(gpt=gpt, vit=vit, vq=VQConfig())
         self.config = gpt
         self.model_type, self.num_classes = gpt.model_type, gpt.num_classes
@@ -92,6 +96,7 @@ class Transformer:
 def _gpt_factory(name):
     def make(**kw):
         kw = dict(kw)
+        kw.pop("condition_token_num", None); kw.pop("image_size", None)      # gpt.py ModelArgs extras (sample_c2i.py:55-56)
         known = {f for f in GPTConfig.__dataclass_fields__}
         extra = {k: kw.pop(k) for k in list(kw) if k not in known}      # training-only ModelArgs (dropouts, ...) are accepted and ignored
         del extra

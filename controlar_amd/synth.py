@@ -40,9 +40,12 @@ def gpt_state_dict(cfg: GPTConfig, vit: ViTConfig, seed: int = 0, ctrl_gain: flo
     ctrl = ctrl_gain * D ** -0.5
     sd: Dict[str, torch.Tensor] = {}
     sd["tok_embeddings.weight"] = r.normal(cfg.vocab_size, D, std=1.0)
-    sd["cls_embedding.cap_proj.fc1.weight"] = r.normal(D, cfg.caption_dim, std=3.0 * cfg.caption_dim ** -0.5)
-    sd["cls_embedding.cap_proj.fc2.weight"] = r.normal(D, D, std=3.0 * D ** -0.5)
-    sd["cls_embedding.uncond_embedding"] = r.normal(cfg.cls_token_num, cfg.caption_dim, std=cfg.caption_dim ** -0.5)
+    if cfg.model_type == "c2i":      # LabelEmbedder (gpt.py:66-96): num_classes + 1 rows, last = CFG null class
+        sd["cls_embedding.embedding_table.weight"] = r.normal(cfg.num_classes + 1, D, std=1.0)
+    else:
+        sd["cls_embedding.cap_proj.fc1.weight"] = r.normal(D, cfg.caption_dim, std=3.0 * cfg.caption_dim ** -0.5)
+        sd["cls_embedding.cap_proj.fc2.weight"] = r.normal(D, D, std=3.0 * D ** -0.5)
+        sd["cls_embedding.uncond_embedding"] = r.normal(cfg.cls_token_num, cfg.caption_dim, std=cfg.caption_dim ** -0.5)
     sd["adapter_mlp.fc1.weight"] = r.normal(D, vit.hidden, std=ctrl_gain * vit.hidden ** -0.5)
     sd["adapter_mlp.fc2.weight"] = r.normal(D, D, std=ctrl)
     sd["condition_mlp.cap_proj.fc1.weight"] = r.normal(D, D, std=ctrl)
@@ -64,8 +67,42 @@ def gpt_state_dict(cfg: GPTConfig, vit: ViTConfig, seed: int = 0, ctrl_gain: flo
     return sd
 
 
+def vit16_state_dict(cfg: ViTConfig, seed: int = 1, prefix: str = "adapter.model.") -> Dict[str, torch.Tensor]:
+    """Names follow HF ViTModel.state_dict() (transformers 5.15.0 modeling_vit.py: layers.{i}.attention.{q,k,v,o}_proj ...)."""
+    r = _Rng(seed)
+    D, M = cfg.hidden, cfg.mlp
+    n_pos = cfg.pos_grid * cfg.pos_grid + 1
+    sd: Dict[str, torch.Tensor] = {}
+    e = prefix + "embeddings."
+    sd[e + "cls_token"] = r.normal(1, 1, D, std=0.02)
+    sd[e + "position_embeddings"] = r.normal(1, n_pos, D, std=0.2)
+    fan_in = 3 * cfg.patch * cfg.patch
+    sd[e + "patch_embeddings.projection.weight"] = r.normal(D, 3, cfg.patch, cfg.patch, std=fan_in ** -0.5)
+    sd[e + "patch_embeddings.projection.bias"] = r.normal(D, std=0.02)
+    for i in range(cfg.layers):
+        p = f"{prefix}layers.{i}."
+        sd[p + "layernorm_before.weight"] = r.normal(D, std=0.1, mean=1.0)
+        sd[p + "layernorm_before.bias"] = r.normal(D, std=0.05)
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            sd[p + f"attention.{n}.weight"] = r.normal(D, D, std=(0.7 if n == "o_proj" else 1.0) * D ** -0.5)
+            sd[p + f"attention.{n}.bias"] = r.normal(D, std=0.02)
+        sd[p + "layernorm_after.weight"] = r.normal(D, std=0.1, mean=1.0)
+        sd[p + "layernorm_after.bias"] = r.normal(D, std=0.05)
+        sd[p + "mlp.fc1.weight"] = r.normal(M, D, std=D ** -0.5)
+        sd[p + "mlp.fc1.bias"] = r.normal(M, std=0.02)
+        sd[p + "mlp.fc2.weight"] = r.normal(D, M, std=0.7 * M ** -0.5)
+        sd[p + "mlp.fc2.bias"] = r.normal(D, std=0.02)
+    sd[prefix + "layernorm.weight"] = r.normal(D, std=0.1, mean=1.0)
+    sd[prefix + "layernorm.bias"] = r.normal(D, std=0.05)
+    sd[prefix + "pooler.dense.weight"] = r.normal(D, D, std=D ** -0.5)      # present in the checkpoint, unused on the path
+    sd[prefix + "pooler.dense.bias"] = torch.zeros(D)
+    return sd
+
+
 def vit_state_dict(cfg: ViTConfig, seed: int = 1, prefix: str = "adapter.model.") -> Dict[str, torch.Tensor]:
     """Names follow HF Dinov2Model.state_dict() (transformers 5.15.0 modeling_dinov2.py)."""
+    if cfg.variant == "vit":
+        return vit16_state_dict(cfg, seed, prefix)
     r = _Rng(seed)
     D, M = cfg.hidden, cfg.mlp
     n_pos = cfg.pos_grid * cfg.pos_grid + 1
@@ -190,6 +227,11 @@ def smooth_control(batch: int, H: int, W: int, seed: int = 1234) -> torch.Tensor
         m = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=True)[0, 0]
         out.append((2.0 * m - 1.0)[None].repeat(3, 1, 1))
     return torch.stack(out)
+
+
+def class_labels(batch: int, num_classes: int, seed: int = 1234) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, num_classes, (batch,), generator=g, dtype=torch.int64)
 
 
 def text_embeddings(batch: int, T: int = 120, caption_dim: int = 2048, seed: int = 1234):

@@ -59,7 +59,10 @@ typedef struct car_config {
     int32_t vq_n_mult;        /* number of entries used in vq_ch_mult (5 for VQ-16) */
     int32_t vq_ch_mult[8];
     float   gn_eps;           /* 1e-6 */
-    int32_t reserved[8];
+    int32_t vit_variant;      /* 0 = HF Dinov2Model (t2i; LayerScale, patch-14 resize)   1 = HF ViTModel (c2i: gpt.py:319, vit_adapter.py:11-15) */
+    int32_t model_type;       /* 0 = t2i (gpt_t2i.py)   1 = c2i (gpt.py: class-label prefix of length 1) */
+    int32_t num_classes;      /* c2i: LabelEmbedder rows = num_classes + 1, CFG null class = num_classes (gpt.py:66-96) */
+    int32_t reserved[5];
 } car_config;
 
 /* sampling parameters — reference: generate.py:59-74 sample(), :134 generate() kwargs */
@@ -117,6 +120,16 @@ int car_encode_control(car_ctx* ctx, const void* img, int32_t img_dtype, int32_t
 int car_generate(car_ctx* ctx, const void* text_emb, int32_t text_dtype, const int64_t* emb_mask,
                  int32_t B, int32_t n_new, int32_t use_control, const car_sampling* sp,
                  int32_t* out_tokens, const int32_t* forced_tokens, float* logits_out, void* stream);
+
+/*
+ * generate() for the class-conditional model — replaces generate.py:134-204 (c2i branch :139-154) over
+ * autoregressive/models/gpt.py.  labels [B] int64 (device).  Prefix length is 1; no pad mask; control_strength
+ * does not exist on this path.  NOTE: in the reference snapshot this branch only runs with cfg_scale <= 1
+ * (generate.py:88 passes control_strength, which gpt.py's forward does not accept); cfg_scale > 1 is
+ * accepted here with the semantics generate.py:140-146 spells out (null class = num_classes).
+ */
+int car_generate_c2i(car_ctx* ctx, const int64_t* labels, int32_t B, int32_t n_new, int32_t use_control, const car_sampling* sp,
+                     int32_t* out_tokens, const int32_t* forced_tokens, float* logits_out, void* stream);
 
 /*
  * VQModel.decode_code(code_b, [B,C,h,w], channel_first=True) — tokenizer/tokenizer_image/vq_model.py:53-56.

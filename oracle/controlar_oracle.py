@@ -147,8 +147,43 @@ def dinov2_forward(sd: Dict[str, Tensor], vit, x: Tensor, prefix: str = "adapter
     return layer_norm(h, sd[prefix + "layernorm.weight"].to(dtype), sd[prefix + "layernorm.bias"].to(dtype), vit.ln_eps)
 
 
+def vit16_forward(sd: Dict[str, Tensor], vit, x: Tensor, prefix: str = "adapter.model.") -> Tensor:
+    """HF ViTModel.forward(x, interpolate_pos_encoding=True) -> last_hidden_state (transformers 5.15.0
+    models/vit/modeling_vit.py:75-160 embeddings + bicubic pos-emb interpolation, :257-287 ViTLayer —
+    pre-LN, no LayerScale, erf-GELU MLP, final LayerNorm :348,:384).  Called by vit_adapter.py:13-15."""
+    dtype = x.dtype
+    B, _, H, W = x.shape
+    p = vit.patch
+    gh, gw = H // p, W // p
+    D, nh = vit.hidden, vit.heads
+    hd = D // nh
+    w = sd[prefix + "embeddings.patch_embeddings.projection.weight"].to(dtype).reshape(D, -1)
+    bias = sd[prefix + "embeddings.patch_embeddings.projection.bias"].to(dtype)
+    patches = x.reshape(B, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, 3 * p * p)
+    tok = F.linear(patches, w, bias)
+    cls = sd[prefix + "embeddings.cls_token"].to(dtype).expand(B, -1, -1)
+    h = torch.cat([cls, tok], dim=1) + dinov2_pos_embed(sd, prefix, gh, gw, dtype)     # same bicubic(align_corners=False) rule
+    for i in range(vit.layers):
+        q = f"{prefix}layers.{i}."
+        g = lambda n: sd[q + n].to(dtype)  # noqa: E731
+        y = layer_norm(h, g("layernorm_before.weight"), g("layernorm_before.bias"), vit.ln_eps)
+        T = y.shape[1]
+        qh = F.linear(y, g("attention.q_proj.weight"), g("attention.q_proj.bias")).view(B, T, nh, hd).transpose(1, 2)
+        kh = F.linear(y, g("attention.k_proj.weight"), g("attention.k_proj.bias")).view(B, T, nh, hd).transpose(1, 2)
+        vh = F.linear(y, g("attention.v_proj.weight"), g("attention.v_proj.bias")).view(B, T, nh, hd).transpose(1, 2)
+        att = torch.softmax((qh.float() @ kh.float().transpose(-1, -2)) * hd ** -0.5, dim=-1)
+        ctx = (att @ vh.float()).to(dtype).transpose(1, 2).reshape(B, T, D)
+        h = F.linear(ctx, g("attention.o_proj.weight"), g("attention.o_proj.bias")) + h
+        y = layer_norm(h, g("layernorm_after.weight"), g("layernorm_after.bias"), vit.ln_eps)
+        h = F.linear(F.gelu(F.linear(y, g("mlp.fc1.weight"), g("mlp.fc1.bias"))), g("mlp.fc2.weight"), g("mlp.fc2.bias")) + h
+    return layer_norm(h, sd[prefix + "layernorm.weight"].to(dtype), sd[prefix + "layernorm.bias"].to(dtype), vit.ln_eps)
+
+
 def control_encoder(sd, cfg, img: Tensor) -> Tensor:
-    """reference: dinov2_adapter.py:26-29 — resize, DINOv2, drop CLS. -> [B, (H/16)(W/16), vit.hidden]"""
+    """t2i — dinov2_adapter.py:26-29: resize, DINOv2, drop CLS.  c2i — vit_adapter.py:13-15: HF ViT-S/16 on the
+    unresized map with interpolated position embeddings, drop CLS.  -> [B, (H/16)(W/16), vit.hidden]"""
+    if getattr(cfg.vit, "variant", "dinov2") == "vit":
+        return vit16_forward(sd, cfg.vit, img)[:, 1:]
     x = to_patch14(img, cfg.gpt.condition_type, cfg.vit.patch)
     return dinov2_forward(sd, cfg.vit, x)[:, 1:]
 
@@ -288,18 +323,26 @@ def generate(sd, cfg, cond: Tensor, max_new_tokens: int, emb_masks: Optional[Ten
     decode_n_tokens :113-131.  ``forced_tokens`` [B,N] switches to the teacher-forced protocol of
     SURVEY.md Appendix G (token fed back = forced token; logits still recorded)."""
     g = cfg.gpt
-    assert g.model_type == "t2i"
-    B, T = cond.shape[0], cond.shape[1]
+    c2i = g.model_type == "c2i"
+    # c2i (reference gpt.py + generate.py:139-154): cond = int64 class labels [B]; prefix length 1 (condition_token_nums = 0,
+    # sample_c2i.py:55); CFG null class = num_classes; no pad mask; no control_strength.  gpt.py:427 hard-casts the control
+    # tokens to bf16 (the reference cannot run c2i in fp32); this restatement keeps `dtype` throughout.
+    B = cond.shape[0]
+    T = 1 if c2i else cond.shape[1]
     stages = {}
-    cond = cond.to(dtype)
+    if not c2i:
+        cond = cond.to(dtype)
     ctrl_in = None
     if condition is not None:
         a = control_encoder(sd, cfg, condition.to(dtype))
         ctrl_in = mlp(a, sd["adapter_mlp.fc1.weight"], sd["adapter_mlp.fc2.weight"])         # generate.py:136-138
         stages["adapter_out"], stages["adapter_mlp_out"] = a, ctrl_in
     use_cfg = cfg_scale > 1.0
-    if use_cfg:                                                                           # generate.py:155-164
-        cond = torch.cat([cond, torch.zeros_like(cond) + sd["cls_embedding.uncond_embedding"].to(dtype)])
+    if use_cfg:                                                                           # generate.py:140-146 / :155-164
+        if c2i:
+            cond = torch.cat([cond, torch.ones_like(cond) * g.num_classes])
+        else:
+            cond = torch.cat([cond, torch.zeros_like(cond) + sd["cls_embedding.uncond_embedding"].to(dtype)])
         if ctrl_in is not None:
             ctrl_in = torch.cat([ctrl_in, torch.zeros_like(ctrl_in)])
     b = cond.shape[0]
@@ -308,8 +351,11 @@ def generate(sd, cfg, cond: Tensor, max_new_tokens: int, emb_masks: Optional[Ten
     if emb_masks is not None:
         fold_pad_mask(st, torch.cat([emb_masks, emb_masks]) if use_cfg else emb_masks, T)
     # ---- prefill (gpt_t2i.py:433-442): text embed + control-token cache
-    st.control_strength = control_strength if use_cfg else 1.0                            # generate.py:87-92 quirk
-    h = mlp(cond, sd["cls_embedding.cap_proj.fc1.weight"], sd["cls_embedding.cap_proj.fc2.weight"])[:, :g.cls_token_num]
+    st.control_strength = (control_strength if use_cfg else 1.0) if not c2i else 1.0      # generate.py:87-92 quirk
+    if c2i:     # LabelEmbedder.forward (gpt.py:89-96)
+        h = sd["cls_embedding.embedding_table.weight"].to(dtype)[cond.long()].unsqueeze(1)
+    else:
+        h = mlp(cond, sd["cls_embedding.cap_proj.fc1.weight"], sd["cls_embedding.cap_proj.fc2.weight"])[:, :g.cls_token_num]
     if ctrl_in is not None:
         ce = mlp(ctrl_in, sd["condition_mlp.cap_proj.fc1.weight"], sd["condition_mlp.cap_proj.fc2.weight"])
         st.ctrl = [mlp(ce, sd[f"condition_layers.{k}.fc1.weight"], sd[f"condition_layers.{k}.fc2.weight"]) for k in range(3)]

@@ -180,6 +180,124 @@ CASES = {
 DEFAULT = ["tiny_canny_cfg1", "tiny_depth_cfg4", "tiny_mr_192x128", "tiny_mr_128x192", "tiny_cfg_interval",
            "tiny_canny_cfg1_bf16", "vq16_real_8x8"]
 
+
+
+# --------------------------------------------------------------------------------------------------
+# Calibration of the fast-mode tolerance at full size: the reference's OWN bf16 path, teacher-forced on
+# the fp32 golden tokens (SURVEY.md Appendix G protocol), against the fp32 golden logits.
+def teacher_forced_reference(model, cond, emb_masks, condition, forced, dtype):
+    """generate.py:134-204 unrolled with decode_one_token fed the forced tokens (cfg_scale = 1)."""
+    T = cond.shape[1]
+    n_new = forced.shape[1]
+    with torch.no_grad():
+        cnd = model.adapter_mlp(model.adapter(condition.to(dtype)))
+        model.setup_caches(max_batch_size=cond.shape[0], max_seq_length=T + n_new, dtype=model.tok_embeddings.weight.dtype)
+        model.causal_mask[:, :, :T] = model.causal_mask[:, :, :T] * emb_masks.unsqueeze(1)
+        eye = torch.eye(model.causal_mask.size(1), model.causal_mask.size(2))
+        model.causal_mask[:] = model.causal_mask * (1 - eye) + eye
+        rows = []
+        with _Tap() as tap:
+            ref_gen.prefill(model, cond.to(dtype), torch.arange(0, T), 1.0, cnd, 1, temperature=1.0, top_k=0, top_p=1.0, sample_logits=False)
+            input_pos = torch.tensor([T], dtype=torch.int)
+            for i in range(n_new - 1):
+                ref_gen.decode_one_token(model, forced[:, i:i + 1].long(), input_pos, 1.0, True, cnd,
+                                         temperature=1.0, top_k=0, top_p=1.0, sample_logits=False)
+                input_pos += 1
+            rows = tap.rows
+    return torch.stack(rows, dim=1)
+
+
+def case_bf16_calibration(base="xl_canny_512_cfg1", mk=lambda: C.xl_t2i(1024, "small", "canny"), threads=8):
+    torch.set_num_threads(threads)
+    gold = np.load(os.path.join(HERE, base + ".npz"))
+    B, H, W, seed, _ = [int(x) for x in gold["meta"]]
+    cfg = mk()
+    gsd, _ = synth.path_state_dicts(cfg, seed=seed)
+    model = build_ref_gpt(cfg, gsd, torch.bfloat16)
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    t0 = time.time()
+    lg = teacher_forced_reference(model, emb, mask, img, torch.from_numpy(gold["tokens"]), torch.bfloat16)
+    steps = gold["logits_steps"]
+    sub = lg[:, steps][:, :, ::4].numpy().astype(np.float32)
+    d = np.abs(sub - gold["logits"])
+    agree = (lg.argmax(-1).numpy() == gold["tokens"])
+    np.savez_compressed(os.path.join(HERE, base + "_refbf16.npz"), ref_bf16_max=np.float32(d.max()), ref_bf16_mean=np.float32(d.mean()),
+                        ref_bf16_agree=np.float32(agree.mean()), threads=np.int64(threads))
+    print(f"{base}: reference bf16 vs fp32 teacher-forced: max|d|={d.max():.4f} mean|d|={d.mean():.4f} argmax agree={agree.mean():.4f} ({time.time()-t0:.0f}s)")
+
+
+CASES["xl_bf16_calibration"] = case_bf16_calibration
+CASES["b_bf16_calibration"] = lambda: case_bf16_calibration("b_canny_256_cfg4_c1", lambda: C.b_t2i(256, "small", "canny"))
+
+
+
+
+# --------------------------------------------------------------------------------------------------
+# c2i (BASELINE config 1): reference autoregressive/models/gpt.py with the HF ViT-S/16 adapter.  gpt.py:427 hard-casts
+# the control tokens to bf16, so the reference only runs this path in bf16 (fp32 raises a dtype error): the golden is
+# the reference's bf16 output at a pinned thread count and pins the oracle within bf16 tolerance (teacher-forced).
+def build_ref_c2i(cfg, sd, dtype):
+    from transformers import ViTConfig, ViTModel
+    from autoregressive.models import gpt as ref_c2i
+    v = cfg.vit
+    transformers.AutoModel.from_pretrained = staticmethod(lambda name, *a, **k: ViTModel(ViTConfig(
+        hidden_size=v.hidden, num_hidden_layers=v.layers, num_attention_heads=v.heads, intermediate_size=v.mlp,
+        image_size=v.image_size, patch_size=v.patch)))
+    g = cfg.gpt
+    m = ref_c2i.Transformer(ref_c2i.ModelArgs(dim=g.dim, n_layer=g.n_layer, n_head=g.n_head, vocab_size=g.vocab_size,
+                                              block_size=g.block_size, num_classes=g.num_classes, cls_token_num=1, model_type="c2i",
+                                              condition_token_num=0, image_size=int(g.block_size ** 0.5) * 16, multiple_of=g.multiple_of))
+    if v.hidden != 384:
+        m.adapter_mlp = ref_c2i.MLP(v.hidden, g.dim, g.dim)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    allowed = ("condition_embeddings.weight", "condition_mlp.uncond_embedding", "condition_norm.weight")
+    assert all(k in allowed for k in missing), missing
+    assert not unexpected, unexpected
+    transformers.AutoModel.from_pretrained = staticmethod(_fake_from_pretrained)
+    return m.to(dtype).eval()
+
+
+def run_c2i(name, cfg, imgs_u8, labels, cfg_scale, threads=8, seed=0):
+    torch.set_num_threads(threads)
+    gsd, _ = synth.path_state_dicts(cfg, seed=seed)
+    model = build_ref_c2i(cfg, gsd, torch.bfloat16)
+    x = torch.from_numpy(imgs_u8).float() / 255          # sample_c2i.py:96-99,106
+    x = (2 * (x - 0.5))[:, None].repeat(1, 3, 1, 1)
+    n_new = (x.shape[2] // 16) * (x.shape[3] // 16)
+    lab = torch.from_numpy(labels).long()
+    with _Tap() as tap, torch.no_grad():
+        toks = ref_gen.generate(model, lab, n_new, condition=x.to(torch.bfloat16), condition_null=None, condition_token_nums=0,
+                                cfg_scale=cfg_scale, cfg_interval=-1, temperature=1.0, top_k=0, top_p=1.0, sample_logits=False)
+    logits = torch.stack(tap.rows, dim=1)
+    top2 = logits.topk(2, dim=-1).values
+    st = 1 if logits.shape[1] * logits.shape[2] <= 64 * 1024 else 8      # big cases keep every 8th step / 4th vocab entry
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), tokens=toks.numpy().astype(np.int32),
+                        logits=logits.numpy()[:, ::st, ::(2 if st == 1 else 4)].astype(np.float16), logits_step_stride=np.int64(st),
+                        margin=(top2[..., 0] - top2[..., 1]).numpy().astype(np.float32), images_u8=imgs_u8, labels=labels,
+                        cfg_scale=np.float32(cfg_scale), meta=np.array([x.shape[0], x.shape[2], x.shape[3], seed, threads], dtype=np.int64))
+    print(f"{name}: distinct={len(np.unique(toks.numpy()))} ref bf16 -> {os.path.getsize(os.path.join(HERE, name + '.npz'))/1e3:.0f} KB")
+
+
+def case_c2i_tiny():
+    g = torch.Generator().manual_seed(11)
+    imgs = ((torch.rand(2, 128, 128, generator=g) > 0.92).numpy() * 255).astype(np.uint8)
+    run_c2i("tiny_c2i_cfg1", C.tiny_c2i(64), imgs, np.array([3, 7], dtype=np.int64), 1.0)
+
+
+def case_c2i_b():
+    """The reference's own fixtures: condition/example/c2i/canny/{650,2312,15000,48850}.png + .npy labels (sample_c2i.py:86-99)."""
+    from PIL import Image
+    ids = [650, 2312, 15000, 48850]
+    imgs = np.stack([np.array(Image.open(os.path.join(REF, f"condition/example/c2i/canny/{i}.png"))) for i in ids]).astype(np.uint8)
+    labels = np.array([int(np.load(os.path.join(REF, f"condition/example/c2i/canny/{i}.npy"))[0]) for i in ids], dtype=np.int64)
+    run_c2i("b_c2i_canny_fixtures_cfg1", C.b_c2i(256), imgs, labels, 1.0)
+
+
+CASES["tiny_c2i_cfg1"] = case_c2i_tiny
+CASES["b_c2i_canny_fixtures_cfg1"] = case_c2i_b
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or DEFAULT
     for n in names:

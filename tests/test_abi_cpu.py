@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "controlar_hip.h")).read()
-    declared = set(re.findall(r"\b(car_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(car_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     lib = L.load()
     for name in declared:

@@ -82,3 +82,27 @@ def test_resize_restatements_match_torch():
     for (o, i) in [(448, 512), (672, 768), (112, 128), (56, 64)]:
         ref = torch.nn.functional.interpolate(torch.arange(i, dtype=torch.float32).view(1, 1, 1, i), size=(1, o), mode="nearest")
         assert torch.equal(O.nearest_src_index(o, i), ref.view(-1).long())
+
+
+@pytest.mark.parametrize("name,mk", [("tiny_c2i_cfg1", lambda: C.tiny_c2i(64)), ("b_c2i_canny_fixtures_cfg1", lambda: C.b_c2i(256))])
+def test_oracle_c2i_tracks_reference_bf16(name, mk, golden_dir):
+    """c2i (BASELINE config 1): the reference only runs in bf16 (gpt.py:427), so its golden pins the oracle
+    teacher-forced within bf16 round-off — for the oracle's bf16 mode and for its fp32 mode (the GPU ground truth)."""
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = mk()
+    B, H, W, seed, threads = [int(x) for x in gold["meta"]]
+    gsd, _ = synth.path_state_dicts(cfg, seed=seed)
+    x = torch.from_numpy(gold["images_u8"]).float() / 255
+    x = (2 * (x - 0.5))[:, None].repeat(1, 3, 1, 1)
+    labels = torch.from_numpy(gold["labels"])
+    forced = torch.from_numpy(gold["tokens"])
+    st = int(gold["logits_step_stride"]); vs = 2 if st == 1 else 4
+    ref = gold["logits"].astype(np.float32)
+    n_new = forced.shape[1]
+    dtypes = [torch.float32] if name.startswith("b_") else [torch.bfloat16, torch.float32]
+    for dtype in dtypes:
+        toks, logits = O.generate(gsd, cfg, labels, n_new, None, cfg_scale=1.0, condition=x, dtype=dtype, forced_tokens=forced, return_logits=True)
+        d = np.abs(logits.numpy()[:, ::st, ::vs] - ref)
+        assert d.max() < 0.8 and d.mean() < 0.08, (dtype, d.max(), d.mean())
+        agree = toks.numpy() == gold["tokens"]
+        assert agree[gold["margin"] > 0.5].all() and agree.mean() > 0.9, (dtype, agree.mean())

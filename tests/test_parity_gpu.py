@@ -177,3 +177,98 @@ def test_dropin_api_matches_reference_signatures():
     # no control image at all (condition=None) is a legal call of the reference too
     t0 = generate(gpt, cs["emb"].cuda(), 8, cs["mask"].cuda(), condition=None, cfg_scale=1.0, sample_logits=False)
     assert tuple(t0.shape) == (cs["B"], 8)
+
+
+def _golden_big(name, mk):
+    import os
+    from tests.cases import GOLDEN
+    from controlar_amd import synth
+    gold = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    B, H, W, seed, _ = [int(x) for x in gold["meta"]]
+    cfg = mk()
+    gsd, _ = synth.path_state_dicts(cfg, seed=seed)
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    return cfg, gold, gsd, img, emb, mask, B, H, W
+
+
+def test_gpt_b_256_tokens_exact_vs_reference():
+    """GPT-B sized model, 256 tokens, cfg 4: exact mode reproduces the reference's greedy tokens bit-for-bit."""
+    from controlar_amd import config as C
+    from controlar_amd.engine import Engine
+    cfg, gold, gsd, img, emb, mask, B, H, W = _golden_big("b_canny_256_cfg4", lambda: C.b_t2i(256, "small", "canny"))
+    eng = Engine(cfg, "fp32"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    toks, logits = eng.generate(emb.cuda(), 256, mask.cuda(), cfg_scale=float(gold["cfg_scale"]), return_logits=True)
+    assert np.array_equal(toks.cpu().numpy(), gold["tokens"])
+    steps = gold["logits_steps"]
+    np.testing.assert_allclose(logits.cpu().numpy()[:, steps][:, :, ::4], gold["logits"], atol=2e-3, rtol=1e-4)
+    eng.close()
+
+
+def test_gpt_xl_512_full_size_exact_and_fast():
+    """BASELINE config at full size (GPT-XL, 512x512, 1024 tokens, B=1): exact mode must match the reference's
+    1024 greedy tokens bit-for-bit (min top-2 margin of this golden: 1.2e-3); fast mode is graded teacher-forced."""
+    from controlar_amd import config as C
+    from controlar_amd.engine import Engine
+    cfg, gold, gsd, img, emb, mask, B, H, W = _golden_big("xl_canny_512_cfg1", lambda: C.xl_t2i(1024, "small", "canny"))
+    steps = gold["logits_steps"]
+    eng = Engine(cfg, "fp32"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    toks, logits = eng.generate(emb.cuda(), 1024, mask.cuda(), cfg_scale=1.0, return_logits=True)
+    eq = toks.cpu().numpy() == gold["tokens"]
+    assert eq.all(), f"first mismatch at {np.argwhere(~eq)[:1].tolist()}, margin there {gold['margin'][~eq][:1]}"
+    np.testing.assert_allclose(logits.cpu().numpy()[:, steps][:, :, ::4], gold["logits"], atol=5e-3, rtol=1e-4)
+    eng.close()
+    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    toks, logits = eng.generate(emb.cuda(), 1024, mask.cuda(), cfg_scale=1.0, forced_tokens=torch.from_numpy(gold["tokens"]), return_logits=True)
+    # tolerance at this depth/width = the reference's OWN bf16-vs-fp32 deviation on the same protocol
+    # (tests/golden/make_golden.py xl_bf16_calibration: max 1.45, mean 0.24, arg-max agreement 91.6 %), with 1.5x head-room
+    import os
+    from tests.cases import GOLDEN
+    cal = np.load(os.path.join(GOLDEN, "xl_canny_512_cfg1_refbf16.npz"))
+    d = np.abs(logits.cpu().numpy()[:, steps][:, :, ::4] - gold["logits"])
+    assert d.max() <= 1.5 * float(cal["ref_bf16_max"]) and d.mean() <= 1.5 * float(cal["ref_bf16_mean"]), (d.max(), d.mean())
+    agree = toks.cpu().numpy() == gold["tokens"]
+    assert agree.mean() >= float(cal["ref_bf16_agree"]) - 0.03, agree.mean()
+    assert agree[gold["margin"] > 2.0 * float(cal["ref_bf16_max"])].all()
+    eng.close()
+
+
+@pytest.mark.parametrize("name,mk", [("tiny_c2i_cfg1", "tiny"), ("b_c2i_canny_fixtures_cfg1", "b")])
+def test_c2i_class_conditional(name, mk):
+    """BASELINE config 1 (LlamaGen c2i + ViT-S/16 control, gpt.py): exact mode vs the fp32 oracle bit-for-bit on tokens;
+    fast mode teacher-forced vs the reference's bf16 golden (the only precision the reference runs c2i in)."""
+    import os
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    from oracle import controlar_oracle as O
+    from tests.cases import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = C.tiny_c2i(64) if mk == "tiny" else C.b_c2i(256)
+    B, H, W, seed, _ = [int(x) for x in gold["meta"]]
+    gsd, _ = synth.path_state_dicts(cfg, seed=seed)
+    x = torch.from_numpy(gold["images_u8"]).float() / 255
+    x = (2 * (x - 0.5))[:, None].repeat(1, 3, 1, 1)
+    labels = torch.from_numpy(gold["labels"])
+    n_new = gold["tokens"].shape[1]
+    n_chk = n_new if mk == "tiny" else 48               # CPU oracle budget for the GPT-B case
+    toks_o, logits_o = O.generate(gsd, cfg, labels, n_chk, None, cfg_scale=1.0, condition=x, return_logits=True)
+    eng = Engine(cfg, "fp32"); eng.load_state_dict(gsd); eng.finalize()
+    a = eng.encode_control(x.cuda(), want_output=True).cpu()
+    ref_a = O.mlp(O.control_encoder(gsd, cfg, x), gsd["adapter_mlp.fc1.weight"], gsd["adapter_mlp.fc2.weight"])
+    np.testing.assert_allclose(a.numpy(), ref_a.numpy(), atol=1e-4, rtol=1e-4)
+    toks, logits = eng.generate(labels.cuda(), n_chk, None, cfg_scale=1.0, return_logits=True)
+    assert np.array_equal(toks.cpu().numpy(), toks_o.numpy())
+    np.testing.assert_allclose(logits.cpu().numpy(), logits_o.numpy(), atol=2e-3, rtol=1e-4)
+    eng.close()
+    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(x.cuda())
+    toks, logits = eng.generate(labels.cuda(), n_new, None, cfg_scale=1.0, forced_tokens=torch.from_numpy(gold["tokens"]), return_logits=True)
+    st = int(gold["logits_step_stride"]); vs = 2 if st == 1 else 4
+    d = np.abs(logits.cpu().numpy()[:, ::st, ::vs] - gold["logits"].astype(np.float32))
+    assert d.max() < 0.8 and d.mean() < 0.08, (d.max(), d.mean())
+    agree = toks.cpu().numpy() == gold["tokens"]
+    assert agree[gold["margin"] > 0.5].all() and agree.mean() > 0.9
+    eng.close()
