@@ -28,6 +28,7 @@ struct SampleP {
     const float* logits; int B, V, use_cfg; float cfg_scale; int cfg_interval;
     const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
     int logits_ks; long logits_stride; int round_bf16;
+    int stochastic; float temperature; int top_k; float top_p; unsigned long long seed; int row0;
 };
 struct AttnP {
     const void* qkv; void* kcache; void* vcache; const float* rope; const int* pos; const unsigned char* emb_mask;
@@ -772,8 +773,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     if (!sp || !out_tokens || B <= 0 || n_new <= 0) FAIL(c, "car_generate: bad arguments");
     const car_config& g = c->cfg;
     const bool c2i = g.model_type == 1;
-    if (sp->sample_logits) FAIL(c, "car_generate: stochastic sampling (sample_logits=True) is not built yet; greedy only");
-    if (sp->top_p < 1.0f) { /* greedy: filtering never changes the arg-max */ }
+    if (sp->sample_logits && g.vocab_size > 32768) FAIL(c, "car_generate: stochastic sampling supports vocab_size <= 32768");
+    if (g.vocab_size % 4) FAIL(c, "car_generate: vocab_size must be a multiple of 4");
     const int T = g.cls_token_num;
     if (n_new > g.block_size) FAIL(c, "car_generate: max_new_tokens %d exceeds block_size %d (rope table rows, gpt_t2i.py:454)", n_new, g.block_size);
     if (use_control && (c->ctrl_B != B || c->ctrl_ntok < n_new)) FAIL(c, "car_generate: control tokens cached for B=%d n=%d, requested B=%d n_new=%d", c->ctrl_B, c->ctrl_ntok, B, n_new);
@@ -911,6 +912,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     SampleP spp; memset(&spp, 0, sizeof(spp));
     spp.logits = logits; spp.B = B; spp.V = V; spp.use_cfg = use_cfg; spp.cfg_scale = sp->cfg_scale; spp.cfg_interval = sp->cfg_interval;
     spp.step_ptr = step; spp.n_new = n_new; spp.out_tokens = (int*)c->tok_out.p; spp.cur_tok = cur; spp.forced = forced_tokens; spp.logits_out = logits_out;
+    spp.stochastic = sp->sample_logits != 0; spp.temperature = sp->temperature; spp.top_k = sp->top_k; spp.top_p = sp->top_p; spp.seed = sp->seed; spp.row0 = 0;
     car_launch_sample_greedy(&spp, st);
     HIPCHK(c, hipEventRecord(c->ev_t1, st));
 
@@ -950,7 +952,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             f.p2 = pbase; pbase += sizes[gi][3]; f.pl = pbase; pbase += sizes[gi][4];
             gr.attn_part = pbase; pbase += (size_t)gr.bg * Hn * gr.nsplit * 66;
             gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: (pos, step) x 4 chains, then cur_tok
-            gr.sp = spp; gr.sp.B = use_cfg ? B : gr.bg; gr.sp.step_ptr = gr.step;   // under CFG (single chain) rows are [cond B | uncond B]
+            gr.sp = spp; gr.sp.row0 = gr.b0; gr.sp.B = use_cfg ? B : gr.bg; gr.sp.step_ptr = gr.step;   // under CFG (single chain) rows are [cond B | uncond B]
             gr.sp.out_tokens = (int*)c->tok_out.p + (size_t)gr.b0 * n_new; gr.sp.cur_tok = cur + gr.b0;
             gr.sp.forced = forced_tokens ? forced_tokens + (size_t)gr.b0 * n_new : nullptr;
             gr.sp.logits_out = logits_out ? logits_out + (size_t)gr.b0 * n_new * V : nullptr;
@@ -973,9 +975,10 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         c->n_dec_kernels *= NG;
     };
     if (nsteps > 0) {
-        char keyb[256];
+        char keyb[512];
         snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%p|%p", b, B, S_max, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval * 4 + NG, (const void*)forced_tokens, (void*)logits_out);
+        { char kb2[160]; snprintf(kb2, sizeof(kb2), "|%d|%g|%d|%g|%llu", sp->sample_logits, (double)sp->temperature, sp->top_k, (double)sp->top_p, (unsigned long long)sp->seed); strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
         bool graph_ok = true;
         if (getenv("CAR_NO_GRAPH")) { /* skip capture */ }
@@ -1012,6 +1015,29 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         for (int i = 0; i < nsteps; ++i) { const double p = T + i; kvb += 2.0 * g.n_layer * D * (double)e * (p + 1); }
         c->stats.decode_algo_bytes = (int64_t)(wbytes * nsteps + kvb * b);
     }
+    return 0;
+}
+
+// sample() of generate.py:59-74 as a standalone entry (tests; also usable by callers that bring their own logits):
+// logits fp32 [rows, V] (rows = 2B under CFG: cond then uncond), out int32 [B].  `step` only feeds the RNG counter / cfg_interval.
+extern "C" int car_sample_logits(car_ctx* c, const float* logits, int32_t B, int32_t V, const car_sampling* sp, int32_t step, int32_t* out, void* stream_) {
+    if (!c || !logits || !sp || !out || B <= 0 || V <= 0 || V % 4 || V > 32768) { if (c) c->err = "car_sample_logits: bad arguments (V must be a multiple of 4, <= 32768)"; return -1; }
+    hipStream_t caller = (hipStream_t)stream_, st = c->stream;
+    NEED(c, c->scal, (size_t)(8 + 2 * B) * 4);
+    int* stepd = (int*)c->scal.p + 1; int* cur = (int*)c->scal.p + 8;
+    fence_in(c, caller);
+    HIPCHK(c, hipMemcpyAsync(stepd, &step, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    SampleP p; memset(&p, 0, sizeof(p));
+    p.logits = logits; p.B = B; p.V = V; p.use_cfg = sp->cfg_scale > 1.0f; p.cfg_scale = sp->cfg_scale; p.cfg_interval = sp->cfg_interval;
+    p.step_ptr = stepd; p.n_new = 1; p.out_tokens = out; p.cur_tok = cur;
+    p.stochastic = sp->sample_logits != 0; p.temperature = sp->temperature; p.top_k = sp->top_k; p.top_p = sp->top_p; p.seed = sp->seed;
+    // out_tokens is indexed [i*n_new + step]: n_new = 1 and a zero step pointer keep it dense; the RNG step goes through row0
+    int zero = 0; HIPCHK(c, hipMemcpyAsync(stepd, &zero, 4, hipMemcpyHostToDevice, st)); HIPCHK(c, hipStreamSynchronize(st));
+    p.row0 = step * 65536;
+    car_launch_sample_greedy(&p, st);
+    fence_out(c, caller);
+    HIPCHK(c, hipGetLastError());
     return 0;
 }
 

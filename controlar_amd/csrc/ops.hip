@@ -464,6 +464,7 @@ struct SampleP {
     const float* logits; int B, V, use_cfg; float cfg_scale; int cfg_interval;
     const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
     int logits_ks; long logits_stride; int round_bf16;   // logits given as split-K partials [ks][b][V]; bf16 rounding of the sum (gpt_t2i.py:470)
+    int stochastic; float temperature; int top_k; float top_p; unsigned long long seed; int row0;   // sample_logits=True path (generate.py:59-74)
 };
 // 4 consecutive logits of `row` starting at column j (V % 4 == 0)
 __device__ inline void sample_logit4(const SampleP& p, long row, int j, float (&v)[4]) {
@@ -510,7 +511,134 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(SampleP p) {
         if (p.use_cfg) p.cur_tok[i + p.B] = fb;
     }
 }
+// ---- stochastic sampling (generate.py:17-74): temperature, top-k (k-th value threshold), top-p (nucleus on the sorted softmax),
+// softmax, multinomial(1).  One 1024-thread block per image; the sorted copy lives in LDS (bitonic sort, descending).
+// RNG: Philox4x32-10 keyed by the caller's seed, counter = (global image row, step): reproducible and order-independent.
+// Ties: filtering is by VALUE threshold (logits >= k-th / nucleus-cut value are kept), which equals the reference's
+// index-based removal whenever the boundary values are distinct.
+__device__ inline void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ inline float philox_uniform(unsigned long long seed, unsigned a, unsigned b) {
+    unsigned c0 = a, c1 = b, c2 = 0x243F6A88u, c3 = 0x85A308D3u, k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);      // [0, 1)
+}
+// exclusive prefix sum of one value per thread over a 1024-thread block (16 waves); returns the block total via `total`
+__device__ inline float block_excl_scan(float v, float* sm /* >= 34 floats */, float& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) sm[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { float a = 0.f; for (int k = 0; k < nw; ++k) { const float t = sm[k]; sm[k] = a; a += t; } sm[32] = a; }
+    __syncthreads();
+    total = sm[32];
+    return sm[w] + inc - v;
+}
+__global__ __launch_bounds__(1024) void sample_stochastic_kernel(SampleP p, int Vp) {
+    extern __shared__ float keys[];          // Vp floats (Vp = pow2 >= V), sorted descending
+    __shared__ float sm[40]; __shared__ int cut_s; __shared__ int tok_s;
+    const int i = blockIdx.x, step = *p.step_ptr, tid = threadIdx.x, nt = blockDim.x;
+    const bool mix = p.use_cfg && !(p.cfg_interval > -1 && (step - 1) > p.cfg_interval);
+    const float invT = 1.0f / fmaxf(p.temperature, 1e-5f);
+    float* lo = p.logits_out ? p.logits_out + ((long)i * p.n_new + step) * p.V : nullptr;
+    auto mixed4 = [&](int j, float (&v)[4]) {
+        sample_logit4(p, i, j, v);
+        if (mix) { float u[4]; sample_logit4(p, i + p.B, j, u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = u[e] + (v[e] - u[e]) * p.cfg_scale; }
+    };
+    for (int j = tid * 4; j < Vp; j += nt * 4) {
+        float v[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (j < p.V) { mixed4(j, v); if (lo) *(float4*)(lo + j) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= invT; }
+        keys[j] = v[0]; keys[j + 1] = v[1]; keys[j + 2] = v[2]; keys[j + 3] = v[3];
+    }
+    __syncthreads();
+    const bool filt = p.top_k > 0 || p.top_p < 1.0f;
+    float thr = -INFINITY;
+    if (filt) {
+        for (int k = 2; k <= Vp; k <<= 1)
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                for (int a = tid; a < Vp; a += nt) {
+                    const int b = a ^ jj;
+                    if (b > a) { const float x = keys[a], y = keys[b]; const bool desc = (a & k) == 0; if ((x < y) == desc) { keys[a] = y; keys[b] = x; } }
+                }
+                __syncthreads();
+            }
+        int kk = p.V;
+        if (p.top_k > 0) { kk = p.top_k < 1 ? 1 : (p.top_k > p.V ? p.V : p.top_k); thr = keys[kk - 1]; }
+        if (p.top_p < 1.0f) {
+            // nucleus over the top-k-filtered sorted logits (values < thr are already -inf there)
+            const float mx = keys[0];
+            const int per = (Vp + nt - 1) / nt, a0 = tid * per;
+            float loc = 0.f;
+            for (int a = a0; a < a0 + per && a < Vp; ++a) { const float v = keys[a]; if (v >= thr && v > -INFINITY) loc += expf(v - mx); }
+            float total; const float excl = block_excl_scan(loc, sm, total);
+            if (tid == 0) cut_s = Vp;
+            __syncthreads();
+            // sorted position a (>= 1) is removed iff cumprob[a-1] > top_p
+            float run = excl;
+            for (int a = a0; a < a0 + per && a < Vp; ++a) {
+                const float v = keys[a];
+                if (a >= 1 && run / total > p.top_p) { atomicMin(&cut_s, a); break; }
+                if (v >= thr && v > -INFINITY) run += expf(v - mx);
+            }
+            __syncthreads();
+            const int cut = cut_s;
+            if (cut < Vp && cut >= 1) thr = fmaxf(thr, keys[cut - 1]);
+        }
+        (void)kk;
+    }
+    // softmax + multinomial over the filtered logits in index order
+    float mx = -INFINITY;
+    if (filt) mx = keys[0];
+    else { for (int j = tid; j < p.V; j += nt) mx = fmaxf(mx, keys[j]); mx = block_max(mx, sm); }
+    __syncthreads();
+    const int per = (p.V / 4 + nt - 1) / nt * 4, j0 = tid * per;      // contiguous chunk per thread, multiple of 4
+    float loc = 0.f;
+    for (int j = j0; j < j0 + per && j < p.V; j += 4) {
+        float v[4]; mixed4(j, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float x = v[e] * invT; if (x >= thr) loc += expf(x - mx); }
+    }
+    float total; const float excl = block_excl_scan(loc, sm, total);
+    const float target = philox_uniform(p.seed, (unsigned)(p.row0 + i), (unsigned)step) * total;
+    if (tid == 0) tok_s = -1;
+    __syncthreads();
+    if (target >= excl && (target < excl + loc || tid == nt - 1)) {
+        float run = excl; int pick = -1, last = -1;
+        for (int j = j0; j < j0 + per && j < p.V; j += 4) {
+            float v[4]; mixed4(j, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float x = v[e] * invT; if (x >= thr) { run += expf(x - mx); last = j + e; if (pick < 0 && run > target) pick = j + e; } }
+        }
+        if (pick < 0) pick = last;
+        if (pick >= 0) atomicMax(&tok_s, pick);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int t = tok_s;
+        if (t < 0) { t = 0; }       // numerically impossible unless all logits are -inf
+        p.out_tokens[(long)i * p.n_new + step] = t;
+        const int fb = p.forced ? p.forced[(long)i * p.n_new + step] : t;
+        p.cur_tok[i] = fb;
+        if (p.use_cfg) p.cur_tok[i + p.B] = fb;
+    }
+}
 extern "C" void car_launch_sample_greedy(const SampleP* p, hipStream_t st) {
+    if (p->stochastic) {
+        int Vp = 4; while (Vp < p->V) Vp <<= 1;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)sample_stochastic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(sample_stochastic_kernel, dim3(p->B), dim3(1024), (size_t)Vp * 4, st, *p, Vp);
+        return;
+    }
     int th = p->V / 4; th = ((th + 63) / 64) * 64; if (th > 1024) th = 1024; if (th < 64) th = 64;
     hipLaunchKernelGGL(sample_greedy_kernel, dim3(p->B), dim3(th), 0, st, *p);
 }

@@ -160,6 +160,20 @@ class Engine:
                         "car_generate")
         return (out, logits) if return_logits else out
 
+    def sample(self, logits: torch.Tensor, cfg_scale: float = 1.0, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
+               sample_logits: bool = True, seed: int = 0, step: int = 0) -> torch.Tensor:
+        """generate.py:59-74 sample() on caller-provided fp32 logits [rows, V] (rows = 2B under CFG) -> int32 [B]."""
+        logits = logits.to(device=self.device, dtype=torch.float32).contiguous()
+        rows, V = logits.shape
+        B = rows // 2 if cfg_scale > 1.0 else rows
+        sp = L.CarSampling()
+        sp.cfg_scale, sp.cfg_interval, sp.temperature, sp.top_k = float(cfg_scale), -1, float(temperature), int(top_k or 0)
+        sp.top_p, sp.sample_logits, sp.seed, sp.control_strength = float(top_p), int(bool(sample_logits)), int(seed), 1.0
+        out = torch.empty(B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.car_sample_logits(self._h, C.c_void_p(logits.data_ptr()), B, V, C.byref(sp), int(step),
+                                               C.c_void_p(out.data_ptr()), C.c_void_p(_stream_ptr())), "car_sample_logits")
+        return out
+
     def vq_decode(self, tokens: torch.Tensor, h: int, w: int) -> torch.Tensor:
         """VQModel.decode_code(tokens, [B,C,h,w]) -> fp32 [B,3,16h,16w]  (vq_model.py:53-56)."""
         tokens = tokens.to(device=self.device, dtype=torch.int32).contiguous().view(-1, h * w)

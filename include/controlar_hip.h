@@ -132,6 +132,15 @@ int car_generate_c2i(car_ctx* ctx, const int64_t* labels, int32_t B, int32_t n_n
                      int32_t* out_tokens, const int32_t* forced_tokens, float* logits_out, void* stream);
 
 /*
+ * sample() — autoregressive/models/generate.py:59-74 (with top_k_top_p_filtering :17-56) on caller-provided logits:
+ * logits fp32 [rows, V] with rows = B, or 2B under CFG (cond rows then uncond rows, mixed as generate.py:105);
+ * greedy (sample_logits = 0) or temperature / top-k / top-p / multinomial with a Philox counter RNG keyed by
+ * (seed, image row, step).  out int32 [B] (device).  The same kernels run inside car_generate's token loop.
+ */
+int car_sample_logits(car_ctx* ctx, const float* logits, int32_t B, int32_t V, const car_sampling* sp, int32_t step,
+                      int32_t* out, void* stream);
+
+/*
  * VQModel.decode_code(code_b, [B,C,h,w], channel_first=True) — tokenizer/tokenizer_image/vq_model.py:53-56.
  * tokens [B,h*w] int32 -> out fp32 NCHW [B,3,16h,16w].
  */

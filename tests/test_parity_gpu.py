@@ -172,8 +172,15 @@ def test_dropin_api_matches_reference_signatures():
     assert np.array_equal(toks.cpu().numpy(), gold["tokens"])
     px = vq.decode_code(toks, [cs["B"], cfg.vq.codebook_embed_dim, cs["H"] // 16, cs["W"] // 16])
     np.testing.assert_allclose(px.cpu().numpy(), gold["pixels"], atol=5e-4, rtol=1e-4)
-    with pytest.raises(RuntimeError):          # stochastic sampling is not built yet: loud, no fallback
-        generate(gpt, cs["emb"].cuda(), 4, cs["mask"].cuda(), condition=cs["img"].cuda(), sample_logits=True)
+    # the reference's default call style: sample_logits=True, top_k, top_p, temperature (sample_t2i.py:163-170)
+    s1 = generate(gpt, cs["emb"].cuda(), 16, cs["mask"].cuda(), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"], temperature=1.0,
+                  top_k=200, top_p=0.95, sample_logits=True, seed=5)
+    s2 = generate(gpt, cs["emb"].cuda(), 16, cs["mask"].cuda(), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"], temperature=1.0,
+                  top_k=200, top_p=0.95, sample_logits=True, seed=5)
+    s3 = generate(gpt, cs["emb"].cuda(), 16, cs["mask"].cuda(), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"], temperature=1.0,
+                  top_k=200, top_p=0.95, sample_logits=True, seed=6)
+    assert torch.equal(s1, s2) and not torch.equal(s1, s3)
+    assert int(s1.min()) >= 0 and int(s1.max()) < cfg.gpt.vocab_size
     # no control image at all (condition=None) is a legal call of the reference too
     t0 = generate(gpt, cs["emb"].cuda(), 8, cs["mask"].cuda(), condition=None, cfg_scale=1.0, sample_logits=False)
     assert tuple(t0.shape) == (cs["B"], 8)
@@ -271,4 +278,33 @@ def test_c2i_class_conditional(name, mk):
     assert d.max() < 0.8 and d.mean() < 0.08, (d.max(), d.mean())
     agree = toks.cpu().numpy() == gold["tokens"]
     assert agree[gold["margin"] > 0.5].all() and agree.mean() > 0.9
+    eng.close()
+
+
+@pytest.mark.parametrize("temperature,top_k,top_p", [(1.0, 0, 1.0), (0.7, 20, 1.0), (1.0, 0, 0.8), (1.3, 40, 0.9)])
+def test_stochastic_sampler_matches_reference_distribution(temperature, top_k, top_p):
+    """sample() with sample_logits=True (generate.py:59-74): RNG streams cannot match torch.multinomial, so parity is
+    distributional — the empirical token histogram of 32768 independent draws vs the reference's filtered softmax."""
+    from oracle import controlar_oracle as O
+    from controlar_amd.engine import Engine
+    cs = load_case("tiny_canny_cfg1")
+    eng = Engine(cs["cfg"], "bf16")
+    V, N = 256, 32768
+    g = torch.Generator().manual_seed(3)
+    row = torch.randn(V, generator=g) * 2.0
+    lg = row[None].repeat(N, 1)
+    toks = eng.sample(lg.cuda(), temperature=temperature, top_k=top_k, top_p=top_p, sample_logits=True, seed=42, step=0).cpu().long()
+    want = torch.softmax(O.top_k_top_p_filtering(row[None] / max(temperature, 1e-5), top_k, top_p), dim=-1)[0]
+    emp = torch.bincount(toks, minlength=V).float() / N
+    assert float(emp[want == 0].sum()) == 0.0                   # nothing outside the filtered support
+    tv = 0.5 * float((emp - want).abs().sum())
+    assert tv < 0.05, tv
+    # greedy through the same entry = lowest-index arg-max
+    lg2 = torch.randn(64, V, generator=g); lg2[:, 7] = lg2.max() + 1; lg2[:, 3] = lg2[:, 7]
+    t = eng.sample(lg2.cuda(), sample_logits=False).cpu()
+    assert torch.equal(t.long(), torch.full((64,), 3))
+    # CFG layout: rows = [cond | uncond]
+    c_, u_ = torch.randn(8, V, generator=g), torch.randn(8, V, generator=g)
+    t = eng.sample(torch.cat([c_, u_]).cuda(), cfg_scale=3.0, sample_logits=False).cpu().long()
+    assert torch.equal(t, (u_ + (c_ - u_) * 3.0).argmax(-1))
     eng.close()
