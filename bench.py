@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--model", default="xl", choices=["xl", "b", "tiny"])
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-vq", action="store_true",
+                    help="run the VQ decode of batch i on a side stream under the token loop of batch i+1 (measured: no gain on MI355X — "
+                         "the token loop is HBM-bound and the decoder's GEMM grids take every CU; kept for experiments)")
     ap.add_argument("--cpu-tokens", type=int, default=48, help="decode tokens timed by the CPU baseline sample")
     return ap.parse_args()
 
@@ -125,11 +128,13 @@ def main():
     n_new = grid * grid
     log("synthesising weights")
     gsd, vsd = synth.path_state_dicts(cfg, seed=0)          # identical on every rank (seeded CPU generator)
+    # Two contexts, as the reference keeps two modules (gpt_model, vq_model).
     eng = Engine(cfg, args.precision, device=dev)
-    log("loading weights into the HIP context")
-    eng.load_state_dict(gsd)
-    eng.load_state_dict(vsd)
-    eng.finalize()
+    vq_eng = Engine(cfg, args.precision, device=dev)
+    log("loading weights into the HIP contexts")
+    eng.load_state_dict(gsd, finalize=True)
+    vq_eng.load_state_dict(vsd, finalize=True)
+    side = torch.cuda.Stream(device=dev)
     log("weights ready")
 
     # ---- inputs: rank 0 draws the global batch, one broadcast over RCCL/xGMI, each rank takes its shard
@@ -151,12 +156,16 @@ def main():
     def one_step():
         eng.encode_control(img)
         toks = eng.generate(emb, n_new, mask, cfg_scale=args.cfg_scale, control_strength=1.0)
-        px = eng.vq_decode(toks, grid, grid)
+        if not args.overlap_vq:
+            return toks, vq_eng.vq_decode(toks, grid, grid)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            px = vq_eng.vq_decode(toks, grid, grid)     # enqueued asynchronously; the next step's generate() does not wait for it
         return toks, px
 
     for _ in range(args.warmup):
         one_step()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()   # waits for the side stream too
     log("warmup done")
     if dist is not None:
         dist.barrier()

@@ -225,6 +225,7 @@ struct LinP {
     int xmode;      // 0: X is bf16 [b][K];  1: X[m][k] = swiglu of fp32 partials [xks][b][2K] in the block-16 interleaved w1|w3 layout
     int xks;
     int b, N, K, KS;
+    int m0, mrows;  // this launch covers rows [m0, m0+mrows) of the b rows (mrows <= 128); partial/X strides use b
 };
 
 template <int NB>
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinP p) {
     for (int c = tid; c < rows * cpr; c += 256) {
         const int m = c / cpr, kc = (c - m * cpr) * 8;
         uint4 v = z4;
-        if (m < p.b) {
-            if (p.xmode == 0) v = *(const uint4*)((const bf16_t*)p.X + (long)m * p.K + k0 + kc);
+        if (m < p.mrows) {
+            if (p.xmode == 0) v = *(const uint4*)((const bf16_t*)p.X + (long)(p.m0 + m) * p.K + k0 + kc);
             else {
                 // hidden index k -> a at column (k/16)*32 + k%16, c at +16 of the interleaved [2K] row; 8 consecutive k stay inside one block of 16
                 const int k = k0 + kc, col = (k >> 4) * 32 + (k & 15);
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinP p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { a[e] = 0.f; g[e] = 0.f; }
                 for (int s = 0; s < p.xks; ++s) {
-                    const float* src = (const float*)p.X + ((long)s * p.b + m) * (2L * p.K) + col;
+                    const float* src = (const float*)p.X + ((long)s * p.b + p.m0 + m) * (2L * p.K) + col;
                     const float4 a0 = *(const float4*)src, a1 = *(const float4*)(src + 4), g0 = *(const float4*)(src + 16), g1 = *(const float4*)(src + 20);
                     a[0] += a0.x; a[1] += a0.y; a[2] += a0.z; a[3] += a0.w; a[4] += a1.x; a[5] += a1.y; a[6] += a1.z; a[7] += a1.w;
                     g[0] += g0.x; g[1] += g0.y; g[2] += g0.z; g[3] += g0.w; g[4] += g1.x; g[5] += g1.y; g[6] += g1.z; g[7] += g1.w;
@@ -310,16 +311,20 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinP p) {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int m = n * 16 + (lane & 15);
-        if (m < p.b) *(f32x4*)(p.part + ((long)ks * p.b + m) * p.N + n0) = acc[n];
+        if (m < p.mrows) *(f32x4*)(p.part + ((long)ks * p.b + p.m0 + m) * p.N + n0) = acc[n];
     }
 }
 
-extern "C" void car_launch_dec_linear(const LinP* p, hipStream_t st) {
-    const int KC = p->K / p->KS;
-    const int NB = (p->b + 15) / 16;
-    dim3 g((p->N + 63) / 64, p->KS);
-    if (NB <= 1) hipLaunchKernelGGL(dec_linear_kernel<1>, g, dim3(256), (size_t)16 * (KC + 8) * 2, st, *p);
-    else if (NB == 2) hipLaunchKernelGGL(dec_linear_kernel<2>, g, dim3(256), (size_t)32 * (KC + 8) * 2, st, *p);
-    else if (NB <= 4) hipLaunchKernelGGL(dec_linear_kernel<4>, g, dim3(256), (size_t)64 * (KC + 8) * 2, st, *p);
-    else hipLaunchKernelGGL(dec_linear_kernel<8>, g, dim3(256), (size_t)128 * (KC + 8) * 2, st, *p);
+// rows are processed in tiles of <= 64 (the dec_linear<4> sweet spot: K-slice of X within 64 KiB of LDS at KC <= 504);
+// a chain with more rows simply issues one launch per tile (weights re-streamed per tile, they sit in the MALL).
+extern "C" void car_launch_dec_linear(const LinP* pp, hipStream_t st) {
+    const int KC = pp->K / pp->KS;
+    dim3 g((pp->N + 63) / 64, pp->KS);
+    for (int m0 = 0; m0 < pp->b; m0 += 64) {
+        LinP p = *pp; p.m0 = m0; p.mrows = (pp->b - m0) < 64 ? (pp->b - m0) : 64;
+        const int NB = (p.mrows + 15) / 16;
+        if (NB <= 1) hipLaunchKernelGGL(dec_linear_kernel<1>, g, dim3(256), (size_t)16 * (KC + 8) * 2, st, p);
+        else if (NB == 2) hipLaunchKernelGGL(dec_linear_kernel<2>, g, dim3(256), (size_t)32 * (KC + 8) * 2, st, p);
+        else hipLaunchKernelGGL(dec_linear_kernel<4>, g, dim3(256), (size_t)64 * (KC + 8) * 2, st, p);
+    }
 }

@@ -39,6 +39,7 @@ struct LinP {
     const bf16_t* W; const void* X; float* part;
     int xmode; int xks;
     int b, N, K, KS;
+    int m0, mrows;
 };
 extern "C" {
 void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
@@ -86,7 +87,7 @@ struct Wt { void* p = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
 struct car_ctx {
     car_config cfg; int mode = 0; size_t esz = 4;
     std::string err;
-    hipStream_t streamx[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_joinx[3] = {nullptr, nullptr, nullptr};
+    hipStream_t streamx[7] = {}; hipEvent_t ev_fork = nullptr, ev_joinx[7] = {};
     hipStream_t stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
     std::unordered_map<std::string, Wt> w;            // packed weights by (reference) name, element type T unless noted
     std::unordered_map<std::string, std::vector<float>> host_keep;   // host fp32 copies needed later (pos-emb, w1/w3 halves)
@@ -143,19 +144,20 @@ extern "C" int car_create(car_ctx** out, const car_config* cfg) {
     car_ctx* c = new car_ctx();
     c->cfg = *cfg; c->mode = cfg->mode; c->esz = cfg->mode == CAR_BF16 ? 2 : 4;
     memset(&c->stats, 0, sizeof(c->stats));
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->streamx[0], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->streamx[1], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->streamx[2], hipStreamNonBlocking) != hipSuccess ||
+    int prio_lo = 0, prio_hi = 0, prio = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // lo = numerically largest = least urgent
+    prio = cfg->stream_priority == 1 ? prio_lo : (cfg->stream_priority == 2 ? prio_hi : 0);
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_joinx[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_joinx[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_joinx[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess || hipEventCreate(&c->ev_t2) != hipSuccess) {
         g_create_err = "car_create: stream/event creation failed"; delete c; return -1;
     }
+    for (int i = 0; i < 7; ++i)
+        if (hipStreamCreateWithPriority(&c->streamx[i], hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&c->ev_joinx[i], hipEventDisableTiming) != hipSuccess) {
+            g_create_err = "car_create: stream/event creation failed"; delete c; return -1;
+        }
     // 2-D RoPE table (gpt_t2i.py:506-519): rows [0,T) zero, then grid*grid rows of (cos,sin) x 32 pairs
     {
         const int T = cfg->cls_token_num, half = 32, quarter = 16;
@@ -192,7 +194,7 @@ extern "C" void car_destroy(car_ctx* c) {
     c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
     (void)hipStreamDestroy(c->stream);
-    for (int i = 0; i < 3; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); }
+    for (int i = 0; i < 7; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); }
     (void)hipEventDestroy(c->ev_fork);
     delete c;
 }
@@ -615,7 +617,7 @@ struct StepBufs { void *h, *xn, *qkv, *att, *mid, *mid2; float* part; float* log
 
 // split-K factor of a decode linear: enough workgroups to cover the chip, X slice within 64 KiB of LDS
 static int pick_ks(int N, int K, int b) {
-    const int rg = (N + 63) / 64, nkb = K / 32, NB = b <= 16 ? 1 : (b <= 32 ? 2 : (b <= 64 ? 4 : 8));
+    const int rg = (N + 63) / 64, nkb = K / 32, NB = b <= 16 ? 1 : (b <= 32 ? 2 : 4);     // rows are tiled by 64 per launch
     const int kc_max = 65536 / (32 * NB) - 8;
     int best = -1;
     for (int d = 1; d <= nkb; ++d) {
@@ -650,8 +652,8 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     const unsigned char* mask = (const unsigned char*)c->maskb.p + (size_t)b0 * g.cls_token_num;
     int nk = 0;
     auto lin = [&](const std::string& wname, const void* X, float* part, int N, int K, int KS) {
-        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + "#pk"); lp.X = X; lp.part = part; lp.xmode = 0; lp.xks = 0; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS;
-        car_launch_dec_linear(&lp, st); ++nk;
+        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + "#pk"); lp.X = X; lp.part = part; lp.xmode = 0; lp.xks = 0; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS; lp.m0 = 0; lp.mrows = b;
+        car_launch_dec_linear(&lp, st); nk += (b + 63) / 64;
     };
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
@@ -805,7 +807,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     { const int wg = b * Hn; while (wg * nsplit < 1024 && nsplit < 16) nsplit *= 2; }
     NEED(c, c->ws[10], (size_t)b * Hn * nsplit * 66 * 4);                     // split-KV partials
     NEED(c, c->ws[11], (size_t)B * (use_control ? n_tok : 1) * D * e);        // condition_mlp output / mlp mid
-    NEED(c, c->scal, (size_t)(8 + b) * 4);
+    NEED(c, c->scal, (size_t)(16 + b) * 4);
     NEED(c, c->tok_out, (size_t)B * n_new * 4);
     NEED(c, c->maskb, (size_t)b * T);
     for (int k = 0; k < 3; ++k) if (use_control) NEED(c, c->ctrl[k], (size_t)b * n_tok * D * e);
@@ -827,10 +829,10 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         HIPCHK(c, hipMemcpyAsync(c->maskb.p, mk.data(), mk.size(), hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));          // mk is a stack-lifetime host buffer
     }
-    int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 8;
+    int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 16;
     {
-        int init[8] = {T, 0, T, 0, T, 0, T, 0};    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
-        HIPCHK(c, hipMemcpyAsync(pos, init, 32, hipMemcpyHostToDevice, st));
+        int init[16] = {T, 0, T, 0, T, 0, T, 0, T, 0, T, 0, T, 0, T, 0};    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
+        HIPCHK(c, hipMemcpyAsync(pos, init, 64, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
 
@@ -926,12 +928,12 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     // two concurrent chains when the batch is large enough and rows are group-separable (no CFG pairing across halves)
     // chains of <= 64 sequences (the dec_linear<4> sweet spot), at most 4
     int NG = (fast && !use_cfg && b >= 32) ? (b <= 64 ? 2 : (b + 63) / 64) : 1;
-    if (NG > 4) NG = 4;
-    if (NG > 1) { const char* ev = getenv("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 4 && b / v >= 8) NG = v; } }
+    if (NG > 8) NG = 8;
+    if (NG > 1) { const char* ev = getenv("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 8 && b / v >= 8) NG = v; } }
     if (getenv("CAR_SINGLE_CHAIN")) NG = 1;
-    Grp grp[4]; memset(grp, 0, sizeof(grp));
+    Grp grp[8]; memset(grp, 0, sizeof(grp));
     if (fast) {
-        size_t tot = 0; size_t sizes[4][5];
+        size_t tot = 0; size_t sizes[8][5];
         for (int gi = 0; gi < NG; ++gi) {
             Grp& gr = grp[gi];
             gr.b0 = (int)((long)b * gi / NG); gr.bg = (int)((long)b * (gi + 1) / NG) - gr.b0;
@@ -951,7 +953,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             f.pq = pbase; pbase += sizes[gi][0]; f.po = pbase; pbase += sizes[gi][1]; f.p13 = pbase; pbase += sizes[gi][2];
             f.p2 = pbase; pbase += sizes[gi][3]; f.pl = pbase; pbase += sizes[gi][4];
             gr.attn_part = pbase; pbase += (size_t)gr.bg * Hn * gr.nsplit * 66;
-            gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: (pos, step) x 4 chains, then cur_tok
+            gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: (pos, step) x 8 chains, then cur_tok
             gr.sp = spp; gr.sp.row0 = gr.b0; gr.sp.B = use_cfg ? B : gr.bg; gr.sp.step_ptr = gr.step;   // under CFG (single chain) rows are [cond B | uncond B]
             gr.sp.out_tokens = (int*)c->tok_out.p + (size_t)gr.b0 * n_new; gr.sp.cur_tok = cur + gr.b0;
             gr.sp.forced = forced_tokens ? forced_tokens + (size_t)gr.b0 * n_new : nullptr;
@@ -1023,8 +1025,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
 extern "C" int car_sample_logits(car_ctx* c, const float* logits, int32_t B, int32_t V, const car_sampling* sp, int32_t step, int32_t* out, void* stream_) {
     if (!c || !logits || !sp || !out || B <= 0 || V <= 0 || V % 4 || V > 32768) { if (c) c->err = "car_sample_logits: bad arguments (V must be a multiple of 4, <= 32768)"; return -1; }
     hipStream_t caller = (hipStream_t)stream_, st = c->stream;
-    NEED(c, c->scal, (size_t)(8 + 2 * B) * 4);
-    int* stepd = (int*)c->scal.p + 1; int* cur = (int*)c->scal.p + 8;
+    NEED(c, c->scal, (size_t)(16 + 2 * B) * 4);
+    int* stepd = (int*)c->scal.p + 1; int* cur = (int*)c->scal.p + 16;
     fence_in(c, caller);
     HIPCHK(c, hipMemcpyAsync(stepd, &step, 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));

@@ -62,7 +62,9 @@ typedef struct car_config {
     int32_t vit_variant;      /* 0 = HF Dinov2Model (t2i; LayerScale, patch-14 resize)   1 = HF ViTModel (c2i: gpt.py:319, vit_adapter.py:11-15) */
     int32_t model_type;       /* 0 = t2i (gpt_t2i.py)   1 = c2i (gpt.py: class-label prefix of length 1) */
     int32_t num_classes;      /* c2i: LabelEmbedder rows = num_classes + 1, CFG null class = num_classes (gpt.py:66-96) */
-    int32_t reserved[5];
+    int32_t stream_priority;  /* priority of the context's internal HIP streams: 0 default, 1 lowest, 2 highest (overlapping a
+                                 compute-bound context with a latency-bound one on the same GPU) */
+    int32_t reserved[4];
 } car_config;
 
 /* sampling parameters — reference: generate.py:59-74 sample(), :134 generate() kwargs */

@@ -308,3 +308,23 @@ def test_stochastic_sampler_matches_reference_distribution(temperature, top_k, t
     t = eng.sample(torch.cat([c_, u_]).cuda(), cfg_scale=3.0, sample_logits=False).cpu().long()
     assert torch.equal(t, (u_ + (c_ - u_) * 3.0).argmax(-1))
     eng.close()
+
+
+def test_cfg_large_batch_single_chain_row_tiling():
+    """CFG keeps one chain of 2B rows; 2B = 144 > 128 exercises the 64-row tiling of dec_linear (64 + 64 + 16)."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    from oracle import controlar_oracle as O
+    cfg = C.tiny_t2i(64, "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    B, H, W, n_new = 72, 128, 128, 12
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    toks_o, logits_o = O.generate(gsd, cfg, emb, n_new, mask, cfg_scale=2.0, condition=img, return_logits=True)
+    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    toks, logits = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=2.0, forced_tokens=toks_o, return_logits=True)
+    d = (logits.cpu() - logits_o).abs()
+    k = float(np.sqrt(2.0 ** 2 + 1.0 ** 2))
+    assert float(d.amax(dim=(1, 2)).max()) <= 0.6 * k and float(d.mean()) <= 0.08 * k, (float(d.max()), float(d.mean()))
+    eng.close()
