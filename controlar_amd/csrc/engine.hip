@@ -62,6 +62,7 @@ void car_launch_advance(int* pos, int* step, hipStream_t st);
 void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st);
 void car_launch_dec_attn(int mode, const AttnP* p, int b, hipStream_t st);
 void car_launch_dec_linear(const LinP* p, hipStream_t st);
+void car_launch_dec_linear_fp8(const LinP* p, const float* wscale, hipStream_t st);
 void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st);
 void car_launch_swiglu_parts(const float* parts, int ks, long stride, void* out, int rows, int hidden, hipStream_t st);
 void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, hipStream_t st);
@@ -136,6 +137,8 @@ extern "C" int car_create(car_ctx** out, const car_config* cfg) {
     if (cfg->dim % cfg->n_head != 0 || cfg->dim / cfg->n_head != 64) { g_create_err = "car_create: head_dim must be 64 (every LlamaGen size)"; return -1; }
     if (cfg->dim % 32 || cfg->ffn_hidden % 32 || cfg->caption_dim % 32 || cfg->vit_hidden % 32 || cfg->vit_mlp % 32) {
         g_create_err = "car_create: dim, ffn_hidden, caption_dim, vit_hidden, vit_mlp must be multiples of 32"; return -1; }
+    if (cfg->decode_weight_fp8 && (cfg->mode != CAR_BF16 || cfg->dim % 64 || cfg->ffn_hidden % 64)) {
+        g_create_err = "car_create: decode_weight_fp8 needs CAR_BF16 mode and dim, ffn_hidden multiples of 64"; return -1; }
     if (cfg->vit_hidden % cfg->vit_heads != 0 || (cfg->vit_hidden / cfg->vit_heads) % 32) { g_create_err = "car_create: ViT head_dim must be a multiple of 32"; return -1; }
     int g = (int)std::lround(std::sqrt((double)cfg->block_size));
     if (g * g != cfg->block_size) { g_create_err = "car_create: block_size must be a square (gpt_t2i.py:352)"; return -1; }
@@ -221,9 +224,64 @@ static int upload(car_ctx* c, const std::string& name, const std::vector<float>&
     return 0;
 }
 
+// fp32 -> OCP e4m3fn (bias 7, max 448, no inf), round-to-nearest-even, saturating
+static unsigned char f32_to_e4m3(float f) {
+    if (f != f) return 0x7f;
+    const unsigned char sign = std::signbit(f) ? 0x80 : 0;
+    float a = std::fabs(f);
+    if (a >= 464.0f) return sign | 0x7e;                       // beyond the midpoint above 448 (and inf): saturate
+    if (a < 0.015625f) {                                        // below 2^-6: subnormal grid of 2^-9
+        const int q = (int)std::nearbyint(a * 512.0f);
+        return sign | (unsigned char)(q >= 8 ? 0x08 : q);
+    }
+    int e; const float m = std::frexp(a, &e);                   // a = m * 2^e, m in [0.5, 1)
+    int ee = e - 1; float mm = m * 2.0f;                        // a = mm * 2^ee, mm in [1, 2)
+    int mant = (int)std::nearbyint((mm - 1.0f) * 8.0f);
+    if (mant == 8) { mant = 0; ++ee; }
+    if (ee > 8 || (ee == 8 && mant > 6)) return sign | 0x7e;
+    return sign | (unsigned char)(((ee + 7) << 3) | mant);
+}
+static float e4m3_to_f32(unsigned char v) {
+    const int e = (v >> 3) & 15, m = v & 7; const float s = (v & 0x80) ? -1.f : 1.f;
+    if (e == 15 && m == 7) return NAN;
+    return s * (e == 0 ? (float)m * 0.001953125f : std::ldexp(1.0f + (float)m / 8.0f, e - 7));
+}
+extern "C" int car_debug_f32_to_e4m3(const float* in, unsigned char* out, int64_t n) {      // host-only helper (tests)
+    if (!in || !out) return -1;
+    for (int64_t i = 0; i < n; ++i) out[i] = f32_to_e4m3(in[i]);
+    return 0;
+}
+
+// fp8 decode weights: per-row scale s_n = amax_n / 448; image [N/16][K/64][64 lanes][16 B] (lane l: row l&15, 8 bytes of
+// k-block 2j then 8 bytes of k-block 2j+1, k offset (l>>4)*8).  `h` is overwritten with the DEQUANTISED values so that the
+// row-major copy used by prefill sees the same effective weights.
+static int upload_packed_fp8(car_ctx* c, const std::string& name, std::vector<float>& h, int N, int K) {
+    if (N % 16 || K % 64) FAIL(c, "%s: fp8 decode packing needs N%%16==0 and K%%64==0 (got %d x %d)", name.c_str(), N, K);
+    std::vector<float> sc((size_t)N);
+    std::vector<unsigned char> q((size_t)N * K);
+    for (int n = 0; n < N; ++n) {
+        float amax = 0.f; for (int k = 0; k < K; ++k) amax = std::fmax(amax, std::fabs(h[(size_t)n * K + k]));
+        const float s = amax > 0.f ? amax / 448.0f : 1.0f; sc[(size_t)n] = s;
+        for (int k = 0; k < K; ++k) { const unsigned char v = f32_to_e4m3(h[(size_t)n * K + k] / s); q[(size_t)n * K + k] = v; h[(size_t)n * K + k] = e4m3_to_f32(v) * s; }
+    }
+    std::vector<unsigned char> pk((size_t)N * K);
+    const int nkp = K / 64;
+    for (int rb = 0; rb < N / 16; ++rb) for (int kp = 0; kp < nkp; ++kp) for (int l = 0; l < 64; ++l) for (int half = 0; half < 2; ++half) {
+        const unsigned char* src = &q[(size_t)(rb * 16 + (l & 15)) * K + (kp * 2 + half) * 32 + (l >> 4) * 8];
+        memcpy(&pk[((((size_t)rb * nkp + kp) * 64 + l) * 2 + half) * 8], src, 8);
+    }
+    Wt t; t.shape = {N, K}; t.numel = (int64_t)N * K;
+    HIPCHK(c, hipMalloc(&t.p, pk.size()));
+    HIPCHK(c, hipMemcpy(t.p, pk.data(), pk.size(), hipMemcpyHostToDevice));
+    auto it = c->w.find(name + "#pk8"); if (it != c->w.end() && it->second.p) (void)hipFree(it->second.p);
+    c->w[name + "#pk8"] = t;
+    return upload(c, name + "#sc", sc, {N}, true);
+}
+
 // dec_linear weight image: [N/16][K/32] chunks of 64 lanes x 8 bf16 (lane l: row l&15, k (l>>4)*8..+8) — decode.hip
-static int upload_packed(car_ctx* c, const std::string& name, const std::vector<float>& h, int N, int K) {
+static int upload_packed(car_ctx* c, const std::string& name, std::vector<float>& h, int N, int K) {
     if (c->mode != CAR_BF16) return 0;
+    if (c->cfg.decode_weight_fp8) return upload_packed_fp8(c, name, h, N, K);
     if (N % 16 || K % 32) FAIL(c, "%s: decode packing needs N%%16==0 and K%%32==0 (got %d x %d)", name.c_str(), N, K);
     std::vector<bf16_t> pk((size_t)N * K);
     const int nkb = K / 32;
@@ -302,8 +360,8 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
             memcpy(&pk[blk * g.dim], &w1[(size_t)r * g.dim], (size_t)g.dim * 4);
             memcpy(&pk[(blk + 16) * g.dim], &w3[(size_t)r * g.dim], (size_t)g.dim * 4);
         }
-        int rc = upload(c, base + "w13.weight", pk, {2 * (int64_t)g.ffn_hidden, g.dim});
-        if (!rc) rc = upload_packed(c, base + "w13.weight", pk, 2 * g.ffn_hidden, g.dim);
+        int rc = upload_packed(c, base + "w13.weight", pk, 2 * g.ffn_hidden, g.dim);     // (fp8: pk becomes the dequantised image)
+        if (!rc) rc = upload(c, base + "w13.weight", pk, {2 * (int64_t)g.ffn_hidden, g.dim});
         c->host_keep.erase(other);
         return rc;
     }
@@ -616,13 +674,14 @@ extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype
 struct StepBufs { void *h, *xn, *qkv, *att, *mid, *mid2; float* part; float* logits; int *pos, *step, *cur; };
 
 // split-K factor of a decode linear: enough workgroups to cover the chip, X slice within 64 KiB of LDS
-static int pick_ks(int N, int K, int b) {
+static int pick_ks(int N, int K, int b, bool pairs = false) {
     const int rg = (N + 63) / 64, nkb = K / 32, NB = b <= 16 ? 1 : (b <= 32 ? 2 : 4);     // rows are tiled by 64 per launch
     const int kc_max = 65536 / (32 * NB) - 8;
     int best = -1;
     for (int d = 1; d <= nkb; ++d) {
         if (nkb % d) continue;
         const int KC = K / d;
+        if (pairs && KC % 64) continue;
         if (KC > kc_max) continue;
         if (best < 0) best = d;
         if (KC < 128) break;
@@ -652,8 +711,10 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     const unsigned char* mask = (const unsigned char*)c->maskb.p + (size_t)b0 * g.cls_token_num;
     int nk = 0;
     auto lin = [&](const std::string& wname, const void* X, float* part, int N, int K, int KS) {
-        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + "#pk"); lp.X = X; lp.part = part; lp.xmode = 0; lp.xks = 0; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS; lp.m0 = 0; lp.mrows = b;
-        car_launch_dec_linear(&lp, st); nk += (b + 63) / 64;
+        const bool f8 = g.decode_weight_fp8 != 0;
+        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + (f8 ? "#pk8" : "#pk")); lp.X = X; lp.part = part; lp.xmode = 0; lp.xks = 0; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS; lp.m0 = 0; lp.mrows = b;
+        if (f8) car_launch_dec_linear_fp8(&lp, (const float*)Wp(c, wname + "#sc"), st); else car_launch_dec_linear(&lp, st);
+        nk += (b + 63) / 64;
     };
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
@@ -940,7 +1001,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             const int bg = gr.bg;
             gr.nsplit = 1; { const int wg = bg * Hn; while (wg * gr.nsplit < 1024 && gr.nsplit < 16) gr.nsplit *= 2; }
             FastBufs& f = gr.fb;
-            f.ksq = pick_ks(3 * D, D, bg); f.kso = pick_ks(D, D, bg); f.ks13 = pick_ks(2 * Fh, D, bg); f.ks2 = pick_ks(D, Fh, bg); f.ksl = pick_ks(V, D, bg);
+            const bool f8 = g.decode_weight_fp8 != 0;
+            f.ksq = pick_ks(3 * D, D, bg, f8); f.kso = pick_ks(D, D, bg, f8); f.ks13 = pick_ks(2 * Fh, D, bg, f8); f.ks2 = pick_ks(D, Fh, bg, f8); f.ksl = pick_ks(V, D, bg, f8);
             sizes[gi][0] = (size_t)f.ksq * bg * 3 * D; sizes[gi][1] = (size_t)f.kso * bg * D; sizes[gi][2] = (size_t)f.ks13 * bg * 2 * Fh;
             sizes[gi][3] = (size_t)f.ks2 * bg * D; sizes[gi][4] = (size_t)f.ksl * bg * V;
             for (int k = 0; k < 5; ++k) tot += sizes[gi][k];
@@ -1012,7 +1074,10 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     {
         c->stats.decode_steps = nsteps;
         c->stats.decode_kernels_per_step = c->n_dec_kernels;
-        const double wbytes = ((double)g.n_layer * ((double)3 * D * D + (double)D * D + 3.0 * (double)Fh * D + 2.0 * D) + D + (double)V * D) * (double)e;
+        const double we = (mode == CAR_BF16 && g.decode_weight_fp8) ? 1.0 : (double)e;      // fp8 decode weights: 1 B/param (+ fp32 row scales)
+        const double wbytes = ((double)g.n_layer * ((double)3 * D * D + (double)D * D + 3.0 * (double)Fh * D) + (double)V * D) * we
+                              + ((double)g.n_layer * 2.0 * D + D) * (double)e
+                              + ((mode == CAR_BF16 && g.decode_weight_fp8) ? 4.0 * ((double)g.n_layer * (5.0 * D + 2.0 * Fh) + V) : 0.0);
         double kvb = 0;
         for (int i = 0; i < nsteps; ++i) { const double p = T + i; kvb += 2.0 * g.n_layer * D * (double)e * (p + 1); }
         c->stats.decode_algo_bytes = (int64_t)(wbytes * nsteps + kvb * b);

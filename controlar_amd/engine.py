@@ -27,7 +27,8 @@ def _dt(t: torch.Tensor) -> int:
 class Engine:
     """One context = one set of weights in one arithmetic mode ('fp32' exact | 'bf16' fast)."""
 
-    def __init__(self, cfg: PathConfig, precision: str = "bf16", device: Optional[torch.device] = None, stream_priority: int = 0):
+    def __init__(self, cfg: PathConfig, precision: str = "bf16", device: Optional[torch.device] = None, stream_priority: int = 0,
+                 weights_fp8: bool = False):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("controlar_amd needs a HIP device (no CPU fallback)")
@@ -56,6 +57,7 @@ class Engine:
         cc.model_type = 1 if g.model_type == "c2i" else 0
         cc.num_classes = g.num_classes
         cc.stream_priority = int(stream_priority)
+        cc.decode_weight_fp8 = int(bool(weights_fp8))          # BASELINE config 5; bf16 mode only
         cc.codebook_size, cc.codebook_dim, cc.z_channels, cc.vq_ch = q.codebook_size, q.codebook_embed_dim, q.z_channels, q.ch
         cc.vq_num_res_blocks, cc.vq_n_mult, cc.gn_eps = q.num_res_blocks, len(q.ch_mult), q.gn_eps
         for i, m in enumerate(q.ch_mult):

@@ -64,7 +64,9 @@ typedef struct car_config {
     int32_t num_classes;      /* c2i: LabelEmbedder rows = num_classes + 1, CFG null class = num_classes (gpt.py:66-96) */
     int32_t stream_priority;  /* priority of the context's internal HIP streams: 0 default, 1 lowest, 2 highest (overlapping a
                                  compute-bound context with a latency-bound one on the same GPU) */
-    int32_t reserved[4];
+    int32_t decode_weight_fp8; /* CAR_BF16 only: the five decode linears (wqkv, wo, w1|w3, w2, output) stream OCP e4m3fn weights with
+                                  per-output-row fp32 scales (BASELINE config 5).  The reference has no fp8 path: tolerance-graded only. */
+    int32_t reserved[3];
 } car_config;
 
 /* sampling parameters — reference: generate.py:59-74 sample(), :134 generate() kwargs */
@@ -159,6 +161,9 @@ typedef struct car_stats {
     int32_t reserved[6];
 } car_stats;
 int car_get_stats(car_ctx* ctx, car_stats* out);
+
+/* Host-only: fp32 -> OCP e4m3fn bytes with the library's rounding (round-to-nearest-even, saturating at 448). */
+int car_debug_f32_to_e4m3(const float* in, unsigned char* out, int64_t n);
 
 /* Copies the cached control tokens of layer-group k (0..2) [b,n_tok,dim] as fp32 to a HOST buffer (tests). */
 int car_debug_control_tokens(car_ctx* ctx, int32_t k, float* host_out, int64_t max_elems);

@@ -56,3 +56,19 @@ def test_engine_refuses_to_run_without_gpu():
     from controlar_amd.engine import Engine
     with pytest.raises(RuntimeError):
         Engine(Cfg.tiny_t2i(), "bf16")
+
+
+def test_e4m3_conversion_matches_torch():
+    """The host-side fp8 quantiser of the fp8-weight decode path (BASELINE config 5) == torch.float8_e4m3fn rounding."""
+    import numpy as np
+    import torch
+    lib = L.load()
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(20000, generator=g) * 100, torch.randn(20000, generator=g) * 0.01, torch.randn(5000, generator=g) * 600,
+                   torch.tensor([0.0, -0.0, 448.0, 463.9, 464.0, 1e9, -1e9, 2 ** -6, 2 ** -9, 2 ** -10, 1.5 * 2 ** -10, 2 ** -7 + 2 ** -10])]).float().contiguous()
+    out = np.empty(x.numel(), dtype=np.uint8)
+    assert lib.car_debug_f32_to_e4m3(C.c_void_p(x.data_ptr()), C.c_void_p(out.ctypes.data), x.numel()) == 0
+    want = x.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).numpy()     # torch saturates only via clamp
+    got_f = torch.from_numpy(out).view(torch.float8_e4m3fn).float()
+    want_f = torch.from_numpy(want).view(torch.float8_e4m3fn).float()
+    assert torch.equal(got_f, want_f)

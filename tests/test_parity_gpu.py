@@ -328,3 +328,50 @@ def test_cfg_large_batch_single_chain_row_tiling():
     k = float(np.sqrt(2.0 ** 2 + 1.0 ** 2))
     assert float(d.amax(dim=(1, 2)).max()) <= 0.6 * k and float(d.mean()) <= 0.08 * k, (float(d.max()), float(d.mean()))
     eng.close()
+
+
+def _quantize_like_library(sd, cfg):
+    """Per-output-row e4m3 quantise/dequantise of the five decode linears, as engine.hip: upload_packed_fp8 does."""
+    out = dict(sd)
+    names = ["output.weight"]
+    for i in range(cfg.gpt.n_layer):
+        p = f"layers.{i}."
+        names += [p + "attention.wqkv.weight", p + "attention.wo.weight", p + "feed_forward.w1.weight", p + "feed_forward.w3.weight", p + "feed_forward.w2.weight"]
+    for n in names:
+        w = sd[n].float()
+        s = w.abs().amax(dim=1, keepdim=True) / 448.0
+        s = torch.where(s > 0, s, torch.ones_like(s))
+        out[n] = (w / s).clamp(-448, 448).to(torch.float8_e4m3fn).float() * s
+    return out
+
+
+def test_fp8_weight_decode_config5():
+    """BASELINE config 5: fp8 (e4m3, per-row scale) decode weights.  Kernel correctness: against the fp32 oracle run on the
+    SAME dequantised weights the fast-mode tolerance must hold; the quantisation error itself (vs the original weights)
+    is reported and bounded loosely (the reference has no fp8 path to compare with)."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    from oracle import controlar_oracle as O
+    cfg = C.tiny_t2i(64, "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    B, H, W, n_new = 8, 128, 128, 32
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    qsd = _quantize_like_library(gsd, cfg)
+    toks_q, logits_q = O.generate(qsd, cfg, emb, n_new, mask, cfg_scale=1.0, condition=img, return_logits=True)
+    toks_o, logits_o = O.generate(gsd, cfg, emb, n_new, mask, cfg_scale=1.0, condition=img, forced_tokens=toks_q, return_logits=True)
+    eng = Engine(cfg, "bf16", weights_fp8=True); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    toks, logits = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=1.0, forced_tokens=toks_q, return_logits=True)
+    d = (logits.cpu() - logits_q).abs()
+    assert d.max() <= 0.6 and d.mean() <= 0.08, (float(d.max()), float(d.mean()))
+    agree = (toks.cpu() == toks_q)
+    top2 = logits_q.topk(2, dim=-1).values
+    assert bool(agree[(top2[..., 0] - top2[..., 1]) > 0.25].all())
+    dq = (logits.cpu() - logits_o).abs()          # total error incl. quantisation
+    print(f"fp8 weights: vs dequantised-weight oracle max {float(d.max()):.3f} mean {float(d.mean()):.4f}; "
+          f"vs original weights max {float(dq.max()):.3f} mean {float(dq.mean()):.4f}")
+    assert dq.mean() <= 0.5
+    with pytest.raises(RuntimeError):
+        Engine(cfg, "fp32", weights_fp8=True)      # fp8 weights exist only in the fast mode
+    eng.close()
