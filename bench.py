@@ -191,6 +191,20 @@ def main():
         assert all_toks.shape[0] == G
     assert bool(torch.isfinite(px).all())
 
+    # HBM-side traffic of one decode step from PMC (profiles/r01_pmc_FETCH_SIZE_b256.txt: rocprofv3 --pmc FETCH_SIZE on
+    # tools/pmc_workload.py, XL, chains of 64; FETCH_SIZE is in KiB and is doubled as MI355X_MICROARCH.md §HBM prescribes for
+    # wide coalesced reads on gfx950).  Per chain of 64 sequences and per layer: w13 19.76 + w2 12.94 + wqkv 11.24 + wo 4.68 +
+    # 2 x rmsnorm 4.25 + swiglu 7.43 MB = 64.55 MB (algorithmic weights: 40.6 MB; the rest is split-K partial re-reads);
+    # per step: + final norm 4.25 + logits 43.4 + sampler 16.8 MB.  dec_attn fetched 12.4 MB at positions 120-124 against
+    # 11.9 MB algorithmic (ratio 1.04), so KV traffic is taken as algorithmic x 1.04.  WRITE_SIZE could not be collected
+    # (the pass did not finish in the GPU budget): the write side is NOT included.
+    def pmc_traffic_per_step(b, kv_bytes_per_step):
+        if args.model != "xl" or args.precision != "bf16":
+            return None
+        chains = 1 if b < 32 else min(8, max(2, (b + 63) // 64)) if args.cfg_scale <= 1.0 else 1
+        per_chain = (36 * 64.55e6 + 4.25e6 + 43.4e6 + 16.8e6) * (min(b / chains, 64) / 64 * 0.37 + 0.63)   # partial traffic scales with rows, weights do not
+        return chains * per_chain + 1.04 * kv_bytes_per_step
+
     if rank == 0:
         value = G * args.steps / elapsed
         per_step_ms = dec_ms / args.steps / max(st["decode_steps"], 1)
@@ -209,7 +223,10 @@ def main():
                        "input_broadcast_s": t_bcast, "graph": st["graph_used"],
                        "decode_kernels_per_step": st["decode_kernels_per_step"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None,
+                         "traffic": pmc_traffic_per_step(args.batch * (2 if args.cfg_scale > 1.0 else 1),
+                                                         st["decode_algo_bytes"] / max(st["decode_steps"], 1) - 1.505e9),
+                         "traffic_note": "read side only, from profiles/r01_pmc_FETCH_SIZE_b256.txt (FETCH_SIZE KiB x 2, gfx950 correction), "
+                                         "scaled to this batch; WRITE_SIZE not collected",
                          "kernel": "decode step (one hipGraph replay = one token for all sequences)",
                          "bytes_per_launch": st["decode_algo_bytes"] / max(st["decode_steps"], 1),
                          "avg_launch_ms": per_step_ms},

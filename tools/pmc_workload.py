@@ -1,0 +1,20 @@
+"""Minimal workload for rocprofv3 --pmc passes (counter collection serialises and slows every dispatch):
+XL weights, B sequences, encode + prefill + a few decode steps at a late position (long KV) — eager launches, one chain."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("CAR_NO_GRAPH", "1")
+pass  # chains stay as in production (eager launches run them back to back on one stream)
+import torch
+from controlar_amd import config as C, synth
+from controlar_amd.engine import Engine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n_new = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+cfg = C.xl_t2i(1024)
+gsd, _ = synth.path_state_dicts(cfg, 0)
+eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+img = synth.canny_like_control(B, 512, 512).to(torch.bfloat16).cuda()
+emb, mask = synth.text_embeddings(B, 120, 2048)
+eng.encode_control(img)
+eng.generate(emb.to(torch.bfloat16).cuda(), n_new, mask.cuda(), cfg_scale=1.0)
+torch.cuda.synchronize()
+print("done", eng.stats())
