@@ -850,6 +850,24 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     hipStream_t caller = (hipStream_t)stream_, st = c->stream;
     const int Tpad = (int)rup(T, 32);
 
+    // ---- row layout.  Images are cut into NG groups; the rows of group g are contiguous: [cond rows | uncond rows] under CFG
+    // (so every group is a self-contained chain for the decode loop), plain image order otherwise.  NG = 1 reproduces the
+    // reference layout [cond 0..B-1 | uncond 0..B-1] (generate.py:158-163).
+    const bool fast = mode == CAR_BF16;
+    const int mult = use_cfg ? 2 : 1;
+    int NG = (fast && b >= 32) ? (b <= 64 ? 2 : (b + 63) / 64) : 1;      // chains of <= 64 rows (the dec_linear<4> sweet spot)
+    if (NG > 8) NG = 8;
+    if (NG > 1) { const char* ev = getenv("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 8 && B / v >= 4) NG = v; } }
+    if (getenv("CAR_SINGLE_CHAIN") || NG > B) NG = 1;
+    int img0[9];
+    for (int gi = 0; gi <= NG; ++gi) img0[gi] = (int)((long)B * gi / NG);
+    std::vector<int> row_img((size_t)b), row_unc((size_t)b);
+    for (int gi = 0; gi < NG; ++gi) {
+        const int ng = img0[gi + 1] - img0[gi], base = mult * img0[gi];
+        for (int j = 0; j < ng; ++j) { row_img[(size_t)base + j] = img0[gi] + j; row_unc[(size_t)base + j] = 0;
+                                       if (use_cfg) { row_img[(size_t)base + ng + j] = img0[gi] + j; row_unc[(size_t)base + ng + j] = 1; } }
+    }
+
     // ---- buffers
     const size_t kv_layer = (size_t)b * Hn * S_max * 64;
     NEED(c, c->kv, (size_t)g.n_layer * 2 * kv_layer * e);
@@ -885,7 +903,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             std::vector<int64_t> hm((size_t)B * T);
             HIPCHK(c, hipStreamSynchronize(st));      // inputs ready (one-time, outside the token loop)
             HIPCHK(c, hipMemcpy(hm.data(), emb_mask, hm.size() * 8, hipMemcpyDeviceToHost));
-            for (int i = 0; i < b; ++i) for (int t = 0; t < T; ++t) mk[(size_t)i * T + t] = hm[(size_t)(i % B) * T + t] != 0;
+            for (int i = 0; i < b; ++i) for (int t = 0; t < T; ++t) mk[(size_t)i * T + t] = hm[(size_t)row_img[(size_t)i] * T + t] != 0;
         }
         HIPCHK(c, hipMemcpyAsync(c->maskb.p, mk.data(), mk.size(), hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));          // mk is a stack-lifetime host buffer
@@ -907,7 +925,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         HIPCHK(c, hipMemcpy(hl.data(), labels, (size_t)B * 8, hipMemcpyDeviceToHost));
         std::vector<int> idx((size_t)b);
         for (int i = 0; i < b; ++i) {
-            const int64_t l = i < B ? hl[(size_t)i] : (int64_t)g.num_classes;
+            const int64_t l = row_unc[(size_t)i] ? (int64_t)g.num_classes : hl[(size_t)row_img[(size_t)i]];
             if (l < 0 || l > g.num_classes) FAIL(c, "car_generate_c2i: class label %lld out of range [0,%d]", (long long)l, g.num_classes);
             idx[(size_t)i] = (int)l;
         }
@@ -916,7 +934,10 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         HIPCHK(c, hipStreamSynchronize(st));
         car_launch_gather_rows(mode, Wp(c, "cls_embedding.embedding_table.weight"), didx, h, b, D, st);
     } else {
-        car_launch_build_text(mode, text_emb, text_dtype, Wp(c, "cls_embedding.uncond_embedding"), text, B, (long)T * g.caption_dim, use_cfg, st);
+        const long per = (long)T * g.caption_dim; const size_t ib = text_dtype == CAR_DT_BF16 ? 2 : 4;
+        for (int gi = 0; gi < NG; ++gi)
+            car_launch_build_text(mode, (const char*)text_emb + (size_t)img0[gi] * per * ib, text_dtype, Wp(c, "cls_embedding.uncond_embedding"),
+                                  off(text, (size_t)mult * img0[gi] * per, e), img0[gi + 1] - img0[gi], per, use_cfg, st);
         mlp_tanh(c, text, g.caption_dim, 0, 1, (int)rowsP, g.caption_dim, "cls_embedding.cap_proj.", xn, h, D, st);
     }
     // ---- C. control tokens: condition_mlp then 3 condition_layers, cached for the whole call (gpt_t2i.py:437-442)
@@ -928,9 +949,11 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         NEED(c, scratch, (size_t)Mc * D * e > (size_t)b * Hn * T * T * 4 ? (size_t)Mc * D * e : (size_t)b * Hn * T * T * 4);
         S = (float*)c->ws[4].p;
         mlp_tanh(c, c->ctrl_in.p, D, 0, 1, Mc, D, "condition_mlp.cap_proj.", scratch.p, ce, D, st);
-        for (int k = 0; k < 3; ++k) {
-            if (use_cfg) HIPCHK(c, hipMemsetAsync(off(c->ctrl[k].p, (size_t)Mc * D, e), 0, (size_t)Mc * D * e, st));   // uncond half: MLP(0) = 0 exactly
-            mlp_tanh(c, ce, D, 0, 1, Mc, D, "condition_layers." + std::to_string(k) + ".", scratch.p, c->ctrl[k].p, D, st);
+        for (int k = 0; k < 3; ++k) for (int gi = 0; gi < NG; ++gi) {
+            const int ng = img0[gi + 1] - img0[gi]; const size_t rows = (size_t)ng * n_tok, base = (size_t)mult * img0[gi] * n_tok;
+            mlp_tanh(c, off(ce, (size_t)img0[gi] * n_tok * D, e), D, 0, 1, (int)rows, D, "condition_layers." + std::to_string(k) + ".", scratch.p,
+                     off(c->ctrl[k].p, base * D, e), D, st);
+            if (use_cfg) HIPCHK(c, hipMemsetAsync(off(c->ctrl[k].p, (base + rows) * D, e), 0, rows * D * e, st));   // uncond rows: MLP(0) = 0 exactly
         }
     }
     // ---- E. prefill over the T prefix rows (gpt_t2i.py:446-470)
@@ -976,7 +999,14 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     spp.logits = logits; spp.B = B; spp.V = V; spp.use_cfg = use_cfg; spp.cfg_scale = sp->cfg_scale; spp.cfg_interval = sp->cfg_interval;
     spp.step_ptr = step; spp.n_new = n_new; spp.out_tokens = (int*)c->tok_out.p; spp.cur_tok = cur; spp.forced = forced_tokens; spp.logits_out = logits_out;
     spp.stochastic = sp->sample_logits != 0; spp.temperature = sp->temperature; spp.top_k = sp->top_k; spp.top_p = sp->top_p; spp.seed = sp->seed; spp.row0 = 0;
-    car_launch_sample_greedy(&spp, st);
+    auto group_sampler = [&](int gi) {      // the sampler of group gi: its rows are [cond ng | uncond ng] starting at row mult*img0[gi]
+        SampleP q = spp; const int i0 = img0[gi], ng = img0[gi + 1] - i0; const size_t rb = (size_t)mult * i0;
+        q.B = ng; q.row0 = i0; q.logits = logits + rb * V; q.out_tokens = (int*)c->tok_out.p + (size_t)i0 * n_new; q.cur_tok = cur + rb;
+        q.forced = forced_tokens ? forced_tokens + (size_t)i0 * n_new : nullptr;
+        q.logits_out = logits_out ? logits_out + (size_t)i0 * n_new * V : nullptr;
+        return q;
+    };
+    for (int gi = 0; gi < NG; ++gi) { SampleP q = group_sampler(gi); car_launch_sample_greedy(&q, st); }
     HIPCHK(c, hipEventRecord(c->ev_t1, st));
 
     // ---- F/G. decode loop: one captured step, replayed n_new-1 times (pos/step/token live on the device)
@@ -985,19 +1015,12 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     sb.part = (float*)c->ws[10].p; sb.logits = logits; sb.pos = pos; sb.step = step; sb.cur = cur;
     const int nsteps = n_new - 1;
     c->stats.graph_used = 0;
-    const bool fast = mode == CAR_BF16;
-    // two concurrent chains when the batch is large enough and rows are group-separable (no CFG pairing across halves)
-    // chains of <= 64 sequences (the dec_linear<4> sweet spot), at most 4
-    int NG = (fast && !use_cfg && b >= 32) ? (b <= 64 ? 2 : (b + 63) / 64) : 1;
-    if (NG > 8) NG = 8;
-    if (NG > 1) { const char* ev = getenv("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 8 && b / v >= 8) NG = v; } }
-    if (getenv("CAR_SINGLE_CHAIN")) NG = 1;
     Grp grp[8]; memset(grp, 0, sizeof(grp));
     if (fast) {
         size_t tot = 0; size_t sizes[8][5];
         for (int gi = 0; gi < NG; ++gi) {
             Grp& gr = grp[gi];
-            gr.b0 = (int)((long)b * gi / NG); gr.bg = (int)((long)b * (gi + 1) / NG) - gr.b0;
+            gr.b0 = mult * img0[gi]; gr.bg = mult * (img0[gi + 1] - img0[gi]);
             const int bg = gr.bg;
             gr.nsplit = 1; { const int wg = bg * Hn; while (wg * gr.nsplit < 1024 && gr.nsplit < 16) gr.nsplit *= 2; }
             FastBufs& f = gr.fb;
@@ -1016,10 +1039,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             f.p2 = pbase; pbase += sizes[gi][3]; f.pl = pbase; pbase += sizes[gi][4];
             gr.attn_part = pbase; pbase += (size_t)gr.bg * Hn * gr.nsplit * 66;
             gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: (pos, step) x 8 chains, then cur_tok
-            gr.sp = spp; gr.sp.row0 = gr.b0; gr.sp.B = use_cfg ? B : gr.bg; gr.sp.step_ptr = gr.step;   // under CFG (single chain) rows are [cond B | uncond B]
-            gr.sp.out_tokens = (int*)c->tok_out.p + (size_t)gr.b0 * n_new; gr.sp.cur_tok = cur + gr.b0;
-            gr.sp.forced = forced_tokens ? forced_tokens + (size_t)gr.b0 * n_new : nullptr;
-            gr.sp.logits_out = logits_out ? logits_out + (size_t)gr.b0 * n_new * V : nullptr;
+            gr.sp = group_sampler(gi); gr.sp.step_ptr = gr.step;
+            gr.sp.logits = nullptr;     // set per launch to the group's logits partials
         }
     }
     bool capturing = false;

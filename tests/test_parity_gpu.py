@@ -310,8 +310,12 @@ def test_stochastic_sampler_matches_reference_distribution(temperature, top_k, t
     eng.close()
 
 
-def test_cfg_large_batch_single_chain_row_tiling():
-    """CFG keeps one chain of 2B rows; 2B = 144 > 128 exercises the 64-row tiling of dec_linear (64 + 64 + 16)."""
+@pytest.mark.parametrize("single_chain", [False, True])
+def test_cfg_large_batch_chains_and_row_tiling(single_chain, monkeypatch):
+    """CFG with 2B = 144 rows: by default the images are cut into 3 groups whose rows are laid out [cond | uncond] per group and
+    decoded as 3 concurrent chains; with CAR_SINGLE_CHAIN the one 144-row chain exercises the 64-row tiling of dec_linear."""
+    if single_chain:
+        monkeypatch.setenv("CAR_SINGLE_CHAIN", "1")
     from controlar_amd import config as C, synth
     from controlar_amd.engine import Engine
     from oracle import controlar_oracle as O
