@@ -37,6 +37,11 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--model", default="xl", choices=["xl", "b", "tiny"])
     ap.add_argument("--image-size", type=int, default=512)
+    ap.add_argument("--image-h", type=int, default=0, help="non-square (MR) height; token grid = H/16 x W/16, rope grid = max side (sample_t2i_MR.py:73-78)")
+    ap.add_argument("--image-w", type=int, default=0)
+    ap.add_argument("--weights-fp8", action="store_true", help="BASELINE config 5: e4m3 decode weights")
+    ap.add_argument("--condition-type", default="canny", help="'canny'/'seg' -> nearest resize, anything else -> bicubic (dinov2_adapter.py:19-23)")
+    ap.add_argument("--adapter-size", default="small", choices=["small", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-vq", action="store_true",
                     help="run the VQ decode of batch i on a side stream under the token loop of batch i+1 (measured: no gain on MI355X — "
@@ -122,14 +127,18 @@ def main():
     from controlar_amd.dist import broadcast_inputs, shard_slice, gather_tokens
 
     S = args.image_size
-    grid = S // 16
-    cfg = {"xl": C.xl_t2i, "b": C.b_t2i, "tiny": C.tiny_t2i}[args.model](grid * grid, condition_type="canny") \
-        if args.model != "tiny" else C.tiny_t2i(grid * grid, "canny")
-    n_new = grid * grid
+    Hh, Ww = (args.image_h or S), (args.image_w or S)
+    gh, gw = Hh // 16, Ww // 16
+    grid = max(gh, gw)
+    if args.model == "tiny":
+        cfg = C.tiny_t2i(grid * grid, args.condition_type)
+    else:
+        cfg = {"xl": C.xl_t2i, "b": C.b_t2i}[args.model](grid * grid, adapter_size=args.adapter_size, condition_type=args.condition_type)
+    n_new = gh * gw
     log("synthesising weights")
     gsd, vsd = synth.path_state_dicts(cfg, seed=0)          # identical on every rank (seeded CPU generator)
     # Two contexts, as the reference keeps two modules (gpt_model, vq_model).
-    eng = Engine(cfg, args.precision, device=dev)
+    eng = Engine(cfg, args.precision, device=dev, weights_fp8=args.weights_fp8)
     vq_eng = Engine(cfg, args.precision, device=dev)
     log("loading weights into the HIP contexts")
     eng.load_state_dict(gsd, finalize=True)
@@ -141,13 +150,13 @@ def main():
     G = args.batch * world
     T, cap = cfg.gpt.cls_token_num, cfg.gpt.caption_dim
     if rank == 0:
-        img = synth.canny_like_control(G, S, S).to(torch.bfloat16)
+        img = (synth.canny_like_control(G, Hh, Ww) if args.condition_type in ("canny", "seg") else synth.smooth_control(G, Hh, Ww)).to(torch.bfloat16)
         emb, mask = synth.text_embeddings(G, T, cap)
         emb = emb.to(torch.bfloat16)
     else:
         img = emb = mask = None
     t_bc0 = time.perf_counter()
-    img, emb, mask = broadcast_inputs(dist, dev, rank, G, S, S, T, cap, img, emb, mask)
+    img, emb, mask = broadcast_inputs(dist, dev, rank, G, Hh, Ww, T, cap, img, emb, mask)
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t_bc0
     sl = shard_slice(G, world, rank)
@@ -157,10 +166,10 @@ def main():
         eng.encode_control(img)
         toks = eng.generate(emb, n_new, mask, cfg_scale=args.cfg_scale, control_strength=1.0)
         if not args.overlap_vq:
-            return toks, vq_eng.vq_decode(toks, grid, grid)
+            return toks, vq_eng.vq_decode(toks, gh, gw)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            px = vq_eng.vq_decode(toks, grid, grid)     # enqueued asynchronously; the next step's generate() does not wait for it
+            px = vq_eng.vq_decode(toks, gh, gw)     # enqueued asynchronously; the next step's generate() does not wait for it
         return toks, px
 
     for _ in range(args.warmup):
@@ -214,7 +223,8 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"LlamaGen-{args.model.upper()} t2i + DINOv2-small canny control, {S}x{S} ({n_new} tokens), "
+            "config": {"workload": f"LlamaGen-{args.model.upper()} t2i + DINOv2-{args.adapter_size} {args.condition_type} control, {Hh}x{Ww} ({n_new} tokens), "
+                                   f"{'fp8 (e4m3) decode weights, ' if args.weights_fp8 else ''}"
                                    f"cfg_scale={args.cfg_scale}, greedy, {args.batch} images/GPU/step; stages A-H "
                                    "(control encoder, generate, VQ decode) all inside the timed region",
                        "images_per_gpu": args.batch, "global_batch": G, "cfg_scale": args.cfg_scale,
@@ -232,7 +242,7 @@ def main():
                          "avg_launch_ms": per_step_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, gsd, vsd, S, S, args.cpu_tokens)
+            out["cpu_baseline"] = cpu_baseline(cfg, gsd, vsd, Hh, Ww, args.cpu_tokens)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
