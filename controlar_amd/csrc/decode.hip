@@ -172,7 +172,7 @@ extern "C" void car_launch_dec_attn(int mode, const AttnP* p, int b, hipStream_t
     dim3 g(p->H, b, p->nsplit);
     if (mode == 1) hipLaunchKernelGGL(dec_attn_kernel<bf16_t>, g, dim3(256), 0, st, *p);
     else hipLaunchKernelGGL(dec_attn_kernel<float>, g, dim3(256), 0, st, *p);
-    if (p->nsplit > 1) {
+    if (p->nsplit > 1 && p->out) {        // out == nullptr: the consumer (dec_linear xmode 2) combines the splits itself
         if (mode == 1) hipLaunchKernelGGL(dec_attn_combine_kernel<bf16_t>, dim3(p->H, b), dim3(64), 0, st, p->part, p->out, p->H, p->nsplit, p->dim);
         else hipLaunchKernelGGL(dec_attn_combine_kernel<float>, dim3(p->H, b), dim3(64), 0, st, p->part, p->out, p->H, p->nsplit, p->dim);
     }
@@ -222,10 +222,12 @@ extern "C" void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* 
 // deterministic, fixed summation order.
 struct LinP {
     const bf16_t* W; const void* X; float* part;
-    int xmode;      // 0: X is bf16 [b][K];  1: X[m][k] = swiglu of fp32 partials [xks][b][2K] in the block-16 interleaved w1|w3 layout
+    int xmode;      // 0: X is bf16 [b][K];  1: X[m][k] = swiglu of fp32 partials [xks][b][2K] in the block-16 interleaved w1|w3 layout;
+                    // 2: X[m][k] = split-KV attention combine of dec_attn partials [b][xh][xks][66] (k = head*64 + d)
     int xks;
     int b, N, K, KS;
     int m0, mrows;  // this launch covers rows [m0, m0+mrows) of the b rows (mrows <= 128); partial/X strides use b
+    int xh;         // xmode 2: number of heads
 };
 
 template <int NB>
@@ -252,7 +254,28 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(LinP p) {
         uint4 v = z4;
         if (m < p.mrows) {
             if (p.xmode == 0) v = *(const uint4*)((const bf16_t*)p.X + (long)(p.m0 + m) * p.K + k0 + kc);
-            else {
+            else if (p.xmode == 2) {
+                // fold the split-KV combine (dec_attn_combine_kernel) into the staging: fixed split order, same arithmetic
+                const int k = k0 + kc, hh = k >> 6, d0 = k & 63;
+                const float* pt = (const float*)p.X + (((long)(p.m0 + m) * p.xh + hh) * p.xks) * 66;
+                float M = -INFINITY;
+                for (int sidx = 0; sidx < p.xks; ++sidx) M = fmaxf(M, pt[sidx * 66]);
+                float L = 0.f, o8[8];
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) o8[e8] = 0.f;
+                for (int sidx = 0; sidx < p.xks; ++sidx) {
+                    const float mm = pt[sidx * 66];
+                    if (mm > -INFINITY) {
+                        const float a = expf(mm - M); L += pt[sidx * 66 + 1] * a;
+#pragma unroll
+                        for (int e8 = 0; e8 < 8; ++e8) o8[e8] += pt[sidx * 66 + 2 + d0 + e8] * a;
+                    }
+                }
+                unsigned o[4];
+#pragma unroll
+                for (int e8 = 0; e8 < 8; e8 += 2) o[e8 >> 1] = (unsigned)f2bf(o8[e8] / L) | ((unsigned)f2bf(o8[e8 + 1] / L) << 16);
+                v = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
                 // hidden index k -> a at column (k/16)*32 + k%16, c at +16 of the interleaved [2K] row; 8 consecutive k stay inside one block of 16
                 const int k = k0 + kc, col = (k >> 4) * 32 + (k & 15);
                 float a[8], g[8];

@@ -40,6 +40,7 @@ struct LinP {
     int xmode; int xks;
     int b, N, K, KS;
     int m0, mrows;
+    int xh;
 };
 extern "C" {
 void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
@@ -710,9 +711,12 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     void* mid = off(sb.mid, (size_t)b0 * Fh, e);
     const unsigned char* mask = (const unsigned char*)c->maskb.p + (size_t)b0 * g.cls_token_num;
     int nk = 0;
-    auto lin = [&](const std::string& wname, const void* X, float* part, int N, int K, int KS) {
+    // small chains (<= 16 rows): the split-KV combine and the SwiGLU are folded into the X staging of the next linear
+    // (2 fewer dependent kernels per layer; the redundant per-workgroup recomputation is negligible at this size)
+    const bool fuse_small = b <= 16 && !g.decode_weight_fp8 && !getenv("CAR_NO_SMALL_FUSE");
+    auto lin = [&](const std::string& wname, const void* X, float* part, int N, int K, int KS, int xmode = 0, int xks = 0) {
         const bool f8 = g.decode_weight_fp8 != 0;
-        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + (f8 ? "#pk8" : "#pk")); lp.X = X; lp.part = part; lp.xmode = 0; lp.xks = 0; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS; lp.m0 = 0; lp.mrows = b;
+        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + (f8 ? "#pk8" : "#pk")); lp.X = X; lp.part = part; lp.xmode = xmode; lp.xks = xks; lp.xh = Hn; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS; lp.m0 = 0; lp.mrows = b;
         if (f8) car_launch_dec_linear_fp8(&lp, (const float*)Wp(c, wname + "#sc"), st); else car_launch_dec_linear(&lp, st);
         nk += (b + 63) / 64;
     };
@@ -730,12 +734,14 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         {
             AttnP ap; memset(&ap, 0, sizeof(ap));
             ap.kcache = off(c->kv.p, (size_t)(2 * l) * kv_layer + kv_off, e); ap.vcache = off(c->kv.p, (size_t)(2 * l + 1) * kv_layer + kv_off, e);
-            ap.rope = c->rope; ap.pos = gr.pos; ap.emb_mask = mask; ap.out = att; ap.part = gr.attn_part;
+            const bool fold = fuse_small && nsplit > 1;
+            ap.rope = c->rope; ap.pos = gr.pos; ap.emb_mask = mask; ap.out = fold ? nullptr : att; ap.part = gr.attn_part;
             ap.H = Hn; ap.S_max = S_max; ap.T = g.cls_token_num; ap.dim = D; ap.nsplit = nsplit;
             ap.qkv_parts = fb.pq; ap.qkv_ks = fb.ksq; ap.qkv_stride = (long)b * 3 * D;
-            car_launch_dec_attn(CAR_BF16, &ap, b, st); nk += nsplit > 1 ? 2 : 1;
+            car_launch_dec_attn(CAR_BF16, &ap, b, st); nk += (nsplit > 1 && !fold) ? 2 : 1;
+            if (fold) lin(L + "attention.wo.weight", gr.attn_part, fb.po, D, D, fb.kso, 2, nsplit);
+            else lin(L + "attention.wo.weight", att, fb.po, D, D, fb.kso);
         }
-        lin(L + "attention.wo.weight", att, fb.po, D, D, fb.kso);
         {   // h += attention output ; ffn_norm -> xn
             NormP np; memset(&np, 0, sizeof(np));
             np.h_in = h; np.h_out = h; np.xn = xn; np.w = Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps;
@@ -743,8 +749,11 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
         }
         lin(L + "feed_forward.w13.weight", xn, fb.p13, 2 * Fh, D, fb.ks13);
-        car_launch_swiglu_parts(fb.p13, fb.ks13, (long)b * 2 * Fh, mid, b, Fh, st); ++nk;
-        lin(L + "feed_forward.w2.weight", mid, fb.p2, D, Fh, fb.ks2);
+        if (fuse_small) lin(L + "feed_forward.w2.weight", fb.p13, fb.p2, D, Fh, fb.ks2, 1, fb.ks13);
+        else {
+            car_launch_swiglu_parts(fb.p13, fb.ks13, (long)b * 2 * Fh, mid, b, Fh, st); ++nk;
+            lin(L + "feed_forward.w2.weight", mid, fb.p2, D, Fh, fb.ks2);
+        }
     }
     {   // h += last FFN output ; final norm
         NormP np; memset(&np, 0, sizeof(np));
