@@ -77,7 +77,7 @@ __device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 enum { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_SILU = 3 };
 enum { BIAS_NONE = 0, BIAS_N = 1, BIAS_M = 2 };
-enum { AMODE_PLAIN = 0, AMODE_CONV3 = 1 };
+enum { AMODE_PLAIN = 0, AMODE_CONV3 = 1, AMODE_CONV3S2 = 2 };
 
 // Generic GEMM descriptor: C[z][m,n] = epi( alpha * sum_k A[z][m,k] * W[z][n,k] )   (both K-contiguous)
 struct GemmP {

@@ -56,6 +56,8 @@ void car_launch_vit_assemble(int mode, const void* tok, const void* cls, const v
 void car_launch_groupnorm(int mode, const void* x, const void* gamma, const void* beta, void* y, float* part, float* stats,
                           int B, int HW, int C, int G, float eps, int swish, hipStream_t st);
 void car_launch_vq_lookup(int mode, const int* tok, const float* cb, const float* wpq, const float* bpq, void* z, long npix, int cd, int zc, int ncode, hipStream_t st);
+void car_launch_conv_in3(int mode, const float* img, const void* w, const void* b, void* out, int B, int H, int W, int Co, hipStream_t st);
+void car_launch_vq_argmin(int mode, const void* z, const float* cb, int* tok, long npix, int cd, int ncode, hipStream_t st);
 void car_launch_conv_out(int mode, const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int C, hipStream_t st);
 void car_launch_swiglu(int mode, const void* in, void* out, long rows, int hidden, hipStream_t st);
 void car_launch_sample_greedy(const SampleP* p, hipStream_t st);
@@ -327,7 +329,7 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
     if (name.find("adapter.model.pooler.") == 0 || name == "condition_norm.weight") return 0;   // present in c2i checkpoints, unused on the path
     // reference tensors that the inference path never reads
     if (name == "condition_embeddings.weight" || name == "condition_mlp.uncond_embedding" || ends_with(name, "mask_token") ||
-        starts_with(name, "encoder.") || starts_with(name, "quant_conv.") || name == "quantize.codebook_used") return 0;
+        name == "quantize.codebook_used") return 0;
     std::vector<int64_t> shp(shape, shape + ndim);
     int64_t n = 1; for (auto s : shp) n *= s;
     // bring to host fp32
@@ -385,7 +387,8 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
         return upload(c, name, pk, {3, 9, C});
     }
     if (name == "decoder.conv_out.bias") return upload(c, name, h, shp, true);
-    if (starts_with(name, "decoder.") && ndim == 4 && shp[2] == 3) {
+    if (name == "encoder.conv_in.weight") return upload(c, name, h, {shp[0], 27});     // [Co,3,3,3] is already (ci, ky, kx)-major
+    if ((starts_with(name, "decoder.") || starts_with(name, "encoder.")) && ndim == 4 && shp[2] == 3) {
         // conv3x3 [Co,Ci,3,3] -> implicit-GEMM weight [Co, 9*Ci], k = tap*Ci + ci
         const int Co = (int)shp[0], Ci = (int)shp[1];
         std::vector<float> pk(h.size());
@@ -393,7 +396,7 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
             pk[((size_t)o * 9 + t) * Ci + ci] = h[((size_t)o * Ci + ci) * 9 + t];
         return upload(c, name, pk, {Co, 9 * (int64_t)Ci});
     }
-    if (starts_with(name, "decoder.") && ndim == 4) return upload(c, name, h, {shp[0], shp[1]});   // 1x1 conv
+    if ((starts_with(name, "decoder.") || starts_with(name, "encoder.") || starts_with(name, "quant_conv.")) && ndim == 4) return upload(c, name, h, {shp[0], shp[1]});   // 1x1 conv
     if (ndim == 2 && (ends_with(name, "attention.wqkv.weight") || ends_with(name, "attention.wo.weight") ||
                       ends_with(name, "feed_forward.w2.weight") || name == "output.weight")) {
         if (upload_packed(c, name, h, (int)shp[0], (int)shp[1])) return -1;
@@ -422,6 +425,26 @@ static std::vector<VqItem> vq_layout(const car_config& g, int* last_c) {
         }
         if (i_level != 0) v.push_back({2, "decoder.conv_blocks." + std::to_string(idx) + ".upsample", block_in, block_in});
     }
+    *last_c = block_in;
+    return v;
+}
+
+static std::vector<VqItem> vq_enc_layout(const car_config& g, int* last_c) {
+    // reference: vq_model.py:62-126 (Encoder).  kind 3 = Downsample
+    std::vector<VqItem> v;
+    const int nres = g.vq_n_mult;
+    int block_in = g.vq_ch;
+    for (int i = 0; i < nres; ++i) {
+        block_in = g.vq_ch * (i == 0 ? 1 : g.vq_ch_mult[i - 1]);
+        const int block_out = g.vq_ch * g.vq_ch_mult[i];
+        for (int j = 0; j < g.vq_num_res_blocks; ++j) {
+            v.push_back({0, "encoder.conv_blocks." + std::to_string(i) + ".res." + std::to_string(j), block_in, block_out});
+            block_in = block_out;
+            if (i == nres - 1) v.push_back({1, "encoder.conv_blocks." + std::to_string(i) + ".attn." + std::to_string(j), block_in, block_in});
+        }
+        if (i != nres - 1) v.push_back({3, "encoder.conv_blocks." + std::to_string(i) + ".downsample", block_in, block_in});
+    }
+    v.push_back({0, "encoder.mid.0", block_in, block_in}); v.push_back({1, "encoder.mid.1", block_in, block_in}); v.push_back({0, "encoder.mid.2", block_in, block_in});
     *last_c = block_in;
     return v;
 }
@@ -468,6 +491,17 @@ extern "C" int car_finalize_weights(car_ctx* c) {
                                 if (it.cin != it.cout) { vr.push_back(it.name + ".nin_shortcut.weight"); vr.push_back(it.name + ".nin_shortcut.bias"); } }
             else if (it.kind == 1) { for (const char* s : {".norm.weight", ".norm.bias", ".q.weight", ".q.bias", ".k.weight", ".k.bias", ".v.weight", ".v.bias", ".proj_out.weight", ".proj_out.bias"}) vr.push_back(it.name + s); }
             else { vr.push_back(it.name + ".conv.weight"); vr.push_back(it.name + ".conv.bias"); }
+        }
+        if (Wp(c, "encoder.conv_in.weight")) {       // encode side is optional as a group, complete if present
+            int el = 0;
+            for (const char* s : {"encoder.conv_in.bias", "encoder.norm_out.weight", "encoder.norm_out.bias", "encoder.conv_out.weight", "encoder.conv_out.bias",
+                                  "quant_conv.weight", "quant_conv.bias"}) vr.push_back(s);
+            for (auto& it : vq_enc_layout(g, &el)) {
+                if (it.kind == 0) { for (const char* s : {".norm1.weight", ".norm1.bias", ".conv1.weight", ".conv1.bias", ".norm2.weight", ".norm2.bias", ".conv2.weight", ".conv2.bias"}) vr.push_back(it.name + s);
+                                    if (it.cin != it.cout) { vr.push_back(it.name + ".nin_shortcut.weight"); vr.push_back(it.name + ".nin_shortcut.bias"); } }
+                else if (it.kind == 1) { for (const char* s : {".norm.weight", ".norm.bias", ".q.weight", ".q.bias", ".k.weight", ".k.bias", ".v.weight", ".v.bias", ".proj_out.weight", ".proj_out.bias"}) vr.push_back(it.name + s); }
+                else { vr.push_back(it.name + ".conv.weight"); vr.push_back(it.name + ".conv.bias"); }
+            }
         }
         for (auto& r : vr) if (!Wp(c, r)) { if (nmiss < 6) missing += r + " "; ++nmiss; }
     }
@@ -1158,6 +1192,98 @@ extern "C" int car_debug_control_tokens(car_ctx* c, int32_t k, float* host_out, 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------- VQ building blocks (shared by decode and encode)
+struct VqOps {
+    car_ctx* c; int mode; size_t e; hipStream_t st;
+    void conv3(const void* x, void* y, const std::string& name, int nb, int Ho, int Wo, int Cin, int Cout, int ups, const void* R, int amode = AMODE_CONV3) const {
+        GemmP q = gp(x, 0, Wp(c, name + ".weight"), 9 * (long)Cin, y, Cout, nb * Ho * Wo, Cout, 9 * Cin);
+        q.bias = Wp(c, name + ".bias"); q.bias_mode = BIAS_N; q.Ho = Ho; q.Wo = Wo; q.Cin = Cin; q.ups = ups; q.R = R; q.ldr = Cout;
+        car_launch_gemm(mode, amode, &q, st);
+    }
+    void conv1(const void* x, void* y, const std::string& name, int M, int Cin, int Cout, const void* R) const {
+        GemmP q = gp(x, Cin, Wp(c, name + ".weight"), Cin, y, Cout, M, Cout, Cin);
+        q.bias = Wp(c, name + ".bias"); q.bias_mode = BIAS_N; q.R = R; q.ldr = Cout;
+        car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+    }
+    void gn(const void* x, void* y, const std::string& name, int nb, int HW, int C, int swish) const {
+        car_launch_groupnorm(mode, x, Wp(c, name + ".weight"), Wp(c, name + ".bias"), y, (float*)c->ws[8].p, (float*)c->ws[9].p, nb, HW, C, 32, c->cfg.gn_eps, swish, st);
+    }
+    // kinds: 0 ResnetBlock (vq_model.py:300-315), 1 AttnBlock (:328-352, single head over HW positions),
+    //        2 Upsample (nearest x2 folded into the conv gather, :375-379), 3 Downsample (pad (0,1,0,1) + conv stride 2, :382-396)
+    void blocks(const std::vector<VqItem>& layout, int nb, void*& x, void*& t1, void*& t2, void*& t3, int& Hc, int& Wc) const {
+        for (auto& it : layout) {
+            const int HW = Hc * Wc;
+            if (it.kind == 0) {
+                gn(x, t1, it.name + ".norm1", nb, HW, it.cin, 1);
+                conv3(t1, t2, it.name + ".conv1", nb, Hc, Wc, it.cin, it.cout, 0, nullptr);
+                gn(t2, t1, it.name + ".norm2", nb, HW, it.cout, 1);
+                if (it.cin != it.cout) { conv1(x, t3, it.name + ".nin_shortcut", nb * HW, it.cin, it.cout, nullptr); conv3(t1, t2, it.name + ".conv2", nb, Hc, Wc, it.cout, it.cout, 0, t3); std::swap(x, t2); }
+                else { conv3(t1, x, it.name + ".conv2", nb, Hc, Wc, it.cout, it.cout, 0, x); }
+            } else if (it.kind == 1) {
+                const int C = it.cin; const int Tp = (int)rup(HW, 32);
+                gn(x, t1, it.name + ".norm", nb, HW, C, 0);
+                void* qb = c->ws[7].p; void* kb = off(qb, (size_t)nb * HW * C, e); void* vb = off(qb, (size_t)2 * nb * HW * C, e);
+                conv1(t1, qb, it.name + ".q", nb * HW, C, C, nullptr); conv1(t1, kb, it.name + ".k", nb * HW, C, C, nullptr); conv1(t1, vb, it.name + ".v", nb * HW, C, C, nullptr);
+                float* S = (float*)c->ws[4].p;
+                { GemmP q = gp(qb, C, kb, C, S, HW, HW, HW, C); q.alpha = 1.0f / std::sqrt((float)C); q.out_f32 = 1; q.nb0 = nb; q.sA0 = (long)HW * C; q.sW0 = (long)HW * C; q.sC0 = (long)HW * HW; car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
+                car_launch_softmax(mode, S, HW, c->ws[5].p, Tp, (long)nb * HW, HW, 0, nullptr, 0, 0, st);
+                car_launch_transpose_pad(mode, vb, C, (long)HW * C, c->ws[6].p, nb, HW, Tp, C, st);
+                { GemmP q = gp(c->ws[5].p, Tp, c->ws[6].p, Tp, t2, C, HW, C, Tp); q.nb0 = nb; q.sA0 = (long)HW * Tp; q.sW0 = (long)C * Tp; q.sC0 = (long)HW * C; car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
+                conv1(t2, x, it.name + ".proj_out", nb * HW, C, C, x);
+            } else if (it.kind == 2) {
+                Hc *= 2; Wc *= 2;
+                conv3(x, t1, it.name + ".conv", nb, Hc, Wc, it.cin, it.cin, 1, nullptr);
+                std::swap(x, t1);
+            } else {
+                Hc /= 2; Wc /= 2;
+                conv3(x, t1, it.name + ".conv", nb, Hc, Wc, it.cin, it.cin, 0, nullptr, AMODE_CONV3S2);
+                std::swap(x, t1);
+            }
+        }
+    }
+};
+
+// VQModel.encode (vq_model.py:41-46) -> min_encoding_indices: img fp32 NCHW [B,3,H,W] (H, W multiples of 16) -> tokens int32 [B, (H/16)(W/16)]
+extern "C" int car_vq_encode(car_ctx* c, const float* img, int32_t B, int32_t H, int32_t W, int32_t* out_tokens, void* stream_) {
+    if (!c) return -1;
+    if (!c->finalized) FAIL(c, "car_vq_encode: call car_finalize_weights first");
+    if (!Wp(c, "encoder.conv_in.weight") || !Wp(c, "quantize.embedding.weight")) FAIL(c, "car_vq_encode: VQ encoder weights were not loaded into this context");
+    const car_config& g = c->cfg; const int mode = c->mode; const size_t e = c->esz;
+    const int ndown = g.vq_n_mult - 1, div = 1 << ndown;
+    if (!img || !out_tokens || B <= 0 || H <= 0 || W <= 0 || H % div || W % div) FAIL(c, "car_vq_encode: bad arguments (H, W must be multiples of %d)", div);
+    if (g.codebook_dim > 16) FAIL(c, "car_vq_encode: codebook_embed_dim > 16 unsupported");
+    hipStream_t caller = (hipStream_t)stream_, st = c->stream;
+    int last_c = 0;
+    const std::vector<VqItem> layout = vq_enc_layout(g, &last_c);
+    const int hh = H / div, ww = W / div, HW0 = hh * ww, HWp = (int)rup(HW0, 32);
+    size_t max_el = (size_t)H * W * g.vq_ch;
+    { size_t hw = (size_t)H * W; for (auto& it : layout) { if (it.kind == 3) hw /= 4; size_t cc = it.cin > it.cout ? it.cin : it.cout; if (hw * cc > max_el) max_el = hw * cc; } }
+    int CH = B; while (CH > 1 && (size_t)CH * max_el * e * 4 > ((size_t)8 << 30)) CH = (CH + 1) / 2;
+    for (int i = 0; i < 4; ++i) NEED(c, c->ws[i], (size_t)CH * max_el * e);
+    NEED(c, c->ws[4], (size_t)CH * HW0 * HW0 * 4);
+    NEED(c, c->ws[5], (size_t)CH * HW0 * HWp * e);
+    NEED(c, c->ws[6], (size_t)CH * last_c * HWp * e);
+    NEED(c, c->ws[7], (size_t)CH * 3 * HW0 * last_c * e);
+    NEED(c, c->ws[8], (size_t)CH * ((size_t)(H * W + 255) / 256) * 2 * 512 * 4 + 1024);
+    NEED(c, c->ws[9], (size_t)CH * 32 * 2 * 4 + 64);
+    fence_in(c, caller);
+    VqOps ops{c, mode, e, st};
+    for (int b0 = 0; b0 < B; b0 += CH) {
+        const int nb = (B - b0) < CH ? (B - b0) : CH;
+        void *x = c->ws[0].p, *t1 = c->ws[1].p, *t2 = c->ws[2].p, *t3 = c->ws[3].p;
+        int Hc = H, Wc = W;
+        car_launch_conv_in3(mode, img + (size_t)b0 * 3 * H * W, Wp(c, "encoder.conv_in.weight"), Wp(c, "encoder.conv_in.bias"), x, nb, H, W, g.vq_ch, st);
+        ops.blocks(layout, nb, x, t1, t2, t3, Hc, Wc);
+        ops.gn(x, t1, "encoder.norm_out", nb, Hc * Wc, last_c, 1);
+        ops.conv3(t1, t2, "encoder.conv_out", nb, Hc, Wc, last_c, g.z_channels, 0, nullptr);
+        ops.conv1(t2, t3, "quant_conv", nb * Hc * Wc, g.z_channels, g.codebook_dim, nullptr);
+        car_launch_vq_argmin(mode, t3, (const float*)Wp(c, "quantize.embedding.weight"), out_tokens + (size_t)b0 * HW0, (long)nb * HW0, g.codebook_dim, g.codebook_size, st);
+    }
+    fence_out(c, caller);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------- VQ decode
 extern "C" int car_vq_decode(car_ctx* c, const int32_t* tokens, int32_t B, int32_t hh, int32_t ww, float* out_nchw, void* stream_) {
     if (!c) return -1;
@@ -1185,19 +1311,7 @@ extern "C" int car_vq_decode(car_ctx* c, const int32_t* tokens, int32_t B, int32
     NEED(c, c->ws[8], (size_t)CH * ((size_t)(Hf * Wf + 255) / 256) * 2 * 512 * 4 + 1024);   // GN partials (C <= 512)
     NEED(c, c->ws[9], (size_t)CH * 32 * 2 * 4 + 64);          // GN stats
     fence_in(c, caller);
-    auto conv3 = [&](const void* x, void* y, const std::string& name, int nb, int Ho, int Wo, int Cin, int Cout, int ups, const void* R) {
-        GemmP q = gp(x, 0, Wp(c, name + ".weight"), 9 * (long)Cin, y, Cout, nb * Ho * Wo, Cout, 9 * Cin);
-        q.bias = Wp(c, name + ".bias"); q.bias_mode = BIAS_N; q.Ho = Ho; q.Wo = Wo; q.Cin = Cin; q.ups = ups; q.R = R; q.ldr = Cout;
-        car_launch_gemm(mode, AMODE_CONV3, &q, st);
-    };
-    auto conv1 = [&](const void* x, void* y, const std::string& name, int M, int Cin, int Cout, const void* R) {
-        GemmP q = gp(x, Cin, Wp(c, name + ".weight"), Cin, y, Cout, M, Cout, Cin);
-        q.bias = Wp(c, name + ".bias"); q.bias_mode = BIAS_N; q.R = R; q.ldr = Cout;
-        car_launch_gemm(mode, AMODE_PLAIN, &q, st);
-    };
-    auto gn = [&](const void* x, void* y, const std::string& name, int nb, int HW, int C, int swish) {
-        car_launch_groupnorm(mode, x, Wp(c, name + ".weight"), Wp(c, name + ".bias"), y, (float*)c->ws[8].p, (float*)c->ws[9].p, nb, HW, C, 32, g.gn_eps, swish, st);
-    };
+    VqOps ops{c, mode, e, st};
     for (int b0 = 0; b0 < B; b0 += CH) {
         const int nb = (B - b0) < CH ? (B - b0) : CH;
         void *x = c->ws[0].p, *t1 = c->ws[1].p, *t2 = c->ws[2].p, *t3 = c->ws[3].p;
@@ -1205,33 +1319,9 @@ extern "C" int car_vq_decode(car_ctx* c, const int32_t* tokens, int32_t B, int32
         // get_codebook_entry + post_quant_conv (vq_model.py:262-277, :49) -> NHWC
         car_launch_vq_lookup(mode, tokens + (size_t)b0 * HW0, (const float*)Wp(c, "quantize.embedding.weight"), (const float*)Wp(c, "post_quant_conv.weight"),
                              (const float*)Wp(c, "post_quant_conv.bias"), t1, (long)nb * HW0, g.codebook_dim, g.z_channels, g.codebook_size, st);
-        conv3(t1, x, "decoder.conv_in", nb, Hc, Wc, g.z_channels, C0, 0, nullptr);
-        for (auto& it : layout) {
-            const int HW = Hc * Wc;
-            if (it.kind == 0) {           // ResnetBlock (vq_model.py:300-315)
-                gn(x, t1, it.name + ".norm1", nb, HW, it.cin, 1);
-                conv3(t1, t2, it.name + ".conv1", nb, Hc, Wc, it.cin, it.cout, 0, nullptr);
-                gn(t2, t1, it.name + ".norm2", nb, HW, it.cout, 1);
-                if (it.cin != it.cout) { conv1(x, t3, it.name + ".nin_shortcut", nb * HW, it.cin, it.cout, nullptr); conv3(t1, t2, it.name + ".conv2", nb, Hc, Wc, it.cout, it.cout, 0, t3); std::swap(x, t2); }
-                else { conv3(t1, x, it.name + ".conv2", nb, Hc, Wc, it.cout, it.cout, 0, x); }
-            } else if (it.kind == 1) {    // AttnBlock (vq_model.py:328-352): single head over HW positions
-                const int C = it.cin; const int Tp = (int)rup(HW, 32);
-                gn(x, t1, it.name + ".norm", nb, HW, C, 0);
-                void* qb = c->ws[7].p; void* kb = off(qb, (size_t)nb * HW * C, e); void* vb = off(qb, (size_t)2 * nb * HW * C, e);
-                conv1(t1, qb, it.name + ".q", nb * HW, C, C, nullptr); conv1(t1, kb, it.name + ".k", nb * HW, C, C, nullptr); conv1(t1, vb, it.name + ".v", nb * HW, C, C, nullptr);
-                float* S = (float*)c->ws[4].p;
-                { GemmP q = gp(qb, C, kb, C, S, HW, HW, HW, C); q.alpha = 1.0f / std::sqrt((float)C); q.out_f32 = 1; q.nb0 = nb; q.sA0 = (long)HW * C; q.sW0 = (long)HW * C; q.sC0 = (long)HW * HW; car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
-                car_launch_softmax(mode, S, HW, c->ws[5].p, Tp, (long)nb * HW, HW, 0, nullptr, 0, 0, st);
-                car_launch_transpose_pad(mode, vb, C, (long)HW * C, c->ws[6].p, nb, HW, Tp, C, st);
-                { GemmP q = gp(c->ws[5].p, Tp, c->ws[6].p, Tp, t2, C, HW, C, Tp); q.nb0 = nb; q.sA0 = (long)HW * Tp; q.sW0 = (long)C * Tp; q.sC0 = (long)HW * C; car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
-                conv1(t2, x, it.name + ".proj_out", nb * HW, C, C, x);
-            } else {                      // Upsample: nearest x2 folded into the conv gather (vq_model.py:375-379)
-                Hc *= 2; Wc *= 2;
-                conv3(x, t1, it.name + ".conv", nb, Hc, Wc, it.cin, it.cin, 1, nullptr);
-                std::swap(x, t1);
-            }
-        }
-        gn(x, t1, "decoder.norm_out", nb, Hc * Wc, last_c, 1);
+        ops.conv3(t1, x, "decoder.conv_in", nb, Hc, Wc, g.z_channels, C0, 0, nullptr);
+        ops.blocks(layout, nb, x, t1, t2, t3, Hc, Wc);
+        ops.gn(x, t1, "decoder.norm_out", nb, Hc * Wc, last_c, 1);
         car_launch_conv_out(mode, t1, Wp(c, "decoder.conv_out.weight"), (const float*)Wp(c, "decoder.conv_out.bias"), out_nchw + (size_t)b0 * 3 * Hf * Wf, nb, Hc, Wc, last_c, st);
     }
     fence_out(c, caller);

@@ -34,7 +34,8 @@ __device__ inline ARow make_arow(const Geo p, int m) {
         const int hw = p.Ho * p.Wo;
         const int b = m / hw, rem = m - b * hw;
         r.y = rem / p.Wo; r.x = rem - r.y * p.Wo;
-        r.base = (long)b * (p.Ho >> p.ups) * (p.Wo >> p.ups);   // in pixels
+        if (AMODE == AMODE_CONV3S2) r.base = (long)b * (p.Ho * 2) * (p.Wo * 2);
+        else r.base = (long)b * (p.Ho >> p.ups) * (p.Wo >> p.ups);   // in pixels
     }
     return r;
 }
@@ -44,6 +45,12 @@ __device__ inline long a_off(const Geo p, const ARow r, int k) {
     if (!r.ok) return -1;
     if (AMODE == AMODE_PLAIN) return r.base + k;
     const int tap = k / p.Cin, c = k - tap * p.Cin;
+    if (AMODE == AMODE_CONV3S2) {
+        // Downsample (vq_model.py:382-396): F.pad(x, (0,1,0,1)) then conv3x3 stride 2, no padding: taps (2y+ty, 2x+tx), zero past the edge
+        const int Hin = p.Ho * 2, Win = p.Wo * 2, yy = 2 * r.y + tap / 3, xx = 2 * r.x + tap % 3;
+        if (yy >= Hin || xx >= Win) return -1;
+        return (r.base + (long)yy * Win + xx) * p.Cin + c;
+    }
     const int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
     if (yy < 0 || yy >= p.Ho || xx < 0 || xx >= p.Wo) return -1;
     return (r.base + (long)(yy >> p.ups) * (p.Wo >> p.ups) + (xx >> p.ups)) * p.Cin + c;
@@ -229,10 +236,12 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
     if (mode == 1) {
         dim3 g((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nb0 * p.nb1);
         if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);
+        else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_CONV3>, g, dim3(256), 0, st, p);
     } else {
         dim3 g((p.N + 63) / 64, (p.M + 63) / 64, p.nb0 * p.nb1);
         if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_f32_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);
+        else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_f32_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm_f32_kernel<AMODE_CONV3>, g, dim3(256), 0, st, p);
     }
 }

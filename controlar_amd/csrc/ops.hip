@@ -407,6 +407,79 @@ extern "C" void car_launch_conv_out(int mode, const void* x, const void* w, cons
     else hipLaunchKernelGGL(conv_out_kernel<float>, dim3((npix + 255) / 256), dim3(256), shb, st, x, w, bias, out, B, H, W, C);
 }
 
+// ------------------------------------------------------------------ VQ encoder entry conv: fp32 NCHW image [B,3,H,W] -> NHWC T [B,H,W,Co]
+// (vq_model.py:68,108 conv_in 3x3 pad 1).  weights [Co][27] in PyTorch order (ci*9 + ky*3 + kx); one lane per pixel, weights in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in3_kernel(const float* img, const void* w_, const void* b_, void* out_, int B, int H, int W, int Co) {
+    extern __shared__ float wsm[];       // [Co][27] + [Co]
+    for (int i = threadIdx.x; i < Co * 27; i += blockDim.x) wsm[i] = ET<T>::ld((const T*)w_ + i);
+    for (int i = threadIdx.x; i < Co; i += blockDim.x) wsm[Co * 27 + i] = ET<T>::ld((const T*)b_ + i);
+    __syncthreads();
+    const long npix = (long)B * H * W, pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H); const long b = pix / ((long)W * H);
+    float in[27];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            in[ci * 9 + t] = (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0.f : ET<T>::rnd(img[((b * 3 + ci) * H + yy) * W + xx]);
+        }
+    T* o = (T*)out_ + pix * Co;
+    for (int co = 0; co < Co; ++co) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) a = fmaf(in[k], wsm[co * 27 + k], a);
+        ET<T>::st(o + co, a + wsm[Co * 27 + co]);
+    }
+}
+extern "C" void car_launch_conv_in3(int mode, const float* img, const void* w, const void* b, void* out, int B, int H, int W, int Co, hipStream_t st) {
+    const long npix = (long)B * H * W; const size_t shb = (size_t)Co * 28 * sizeof(float);
+    if (mode == 1) hipLaunchKernelGGL(conv_in3_kernel<bf16_t>, dim3((npix + 255) / 256), dim3(256), shb, st, img, w, b, out, B, H, W, Co);
+    else hipLaunchKernelGGL(conv_in3_kernel<float>, dim3((npix + 255) / 256), dim3(256), shb, st, img, w, b, out, B, H, W, Co);
+}
+
+// ------------------------------------------------------------------ VectorQuantizer.forward arg-min (vq_model.py:216-232)
+// z NHWC T [npix, cd] ; both z and the codebook are l2-normalised (F.normalize eps 1e-12);
+// d_j = |z|^2 + |e_j|^2 - 2 z.e_j in fp32 ; token = first index of the minimum.  One block per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void vq_argmin_kernel(const void* z_, const float* cb, int* tok, int cd, int ncode) {
+    __shared__ float smv[4]; __shared__ int smi[4];
+    const long pix = blockIdx.x;
+    float z[16]; float zn = 0.f;
+    for (int k = 0; k < cd; ++k) { z[k] = ET<T>::ld((const T*)z_ + pix * cd + k); zn += z[k] * z[k]; }
+    const float zi = 1.0f / fmaxf(sqrtf(zn), 1e-12f);
+    float z2 = 0.f;
+    for (int k = 0; k < cd; ++k) { z[k] *= zi; z2 += z[k] * z[k]; }
+    float best = INFINITY; int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < ncode; j += blockDim.x) {
+        const float* e = cb + (long)j * cd;
+        float en = 0.f;
+        for (int k = 0; k < cd; ++k) en += e[k] * e[k];
+        const float ei = 1.0f / fmaxf(sqrtf(en), 1e-12f);
+        float e2 = 0.f, dot = 0.f;
+        for (int k = 0; k < cd; ++k) { const float v = e[k] * ei; e2 += v * v; dot = fmaf(z[k], v, dot); }
+        const float d = z2 + e2 - 2.0f * dot;
+        if (d < best) { best = d; bi = j; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smv[w] = best; smi[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) if (smv[k] < best || (smv[k] == best && smi[k] < bi)) { best = smv[k]; bi = smi[k]; }
+        tok[pix] = bi;
+    }
+}
+extern "C" void car_launch_vq_argmin(int mode, const void* z, const float* cb, int* tok, long npix, int cd, int ncode, hipStream_t st) {
+    if (mode == 1) hipLaunchKernelGGL(vq_argmin_kernel<bf16_t>, dim3(npix), dim3(256), 0, st, z, cb, tok, cd, ncode);
+    else hipLaunchKernelGGL(vq_argmin_kernel<float>, dim3(npix), dim3(256), 0, st, z, cb, tok, cd, ncode);
+}
+
 // ------------------------------------------------------------------ exact-mode SwiGLU on the block-16 interleaved w1|w3 layout
 template <typename T>
 __global__ void swiglu_kernel(const void* in_, void* out_, long rows, int hidden) {

@@ -187,6 +187,16 @@ class Engine:
                                            C.c_void_p(_stream_ptr())), "car_vq_decode")
         return out
 
+    def vq_encode(self, img: torch.Tensor) -> torch.Tensor:
+        """VQModel.encode(img) -> min_encoding_indices int32 [B, (H/16)(W/16)]  (vq_model.py:41-46)."""
+        img = img.to(device=self.device, dtype=torch.float32).contiguous()
+        B, _, H, W = img.shape
+        down = 2 ** (len(self.cfg.vq.ch_mult) - 1)
+        out = torch.empty(B, (H // down) * (W // down), dtype=torch.int32, device=self.device)
+        self._check(self.lib.car_vq_encode(self._h, C.c_void_p(img.data_ptr()), B, H, W, C.c_void_p(out.data_ptr()), C.c_void_p(_stream_ptr())),
+                    "car_vq_encode")
+        return out
+
     def stats(self) -> dict:
         s = L.CarStats()
         self._check(self.lib.car_get_stats(self._h, C.byref(s)), "car_get_stats")

@@ -153,6 +153,15 @@ class VQModel:
         return self.engine.vq_decode(code_b.reshape(B, h * w), h, w)
 
 
+    def encode_indices(self, x):
+        """min_encoding_indices of VQModel.encode(x) (vq_model.py:41-46 -> info[2]) as int32 [B, h*w]."""
+        return self.engine.vq_encode(x)
+
+
+VQModel.encode_indices = encode_indices
+del encode_indices
+
+
 def VQ_16(**kw):
     return VQModel(VQConfig(ch_mult=(1, 1, 2, 2, 4), **kw))
 

@@ -167,6 +167,27 @@ def vq_decoder_layout(cfg: VQConfig):
     return out, block_in
 
 
+def vq_encoder_layout(cfg: VQConfig):
+    """Encoder module list in execution order (reference vq_model.py:62-126).
+    Items: ("res", name, cin, cout) | ("attn", name, c) | ("down", name, c)."""
+    nres = len(cfg.ch_mult)
+    in_mult = (1,) + tuple(cfg.ch_mult)
+    out = []
+    block_in = cfg.ch
+    for i_level in range(nres):
+        block_in = cfg.ch * in_mult[i_level]
+        block_out = cfg.ch * cfg.ch_mult[i_level]
+        for j in range(cfg.num_res_blocks):
+            out.append(("res", f"encoder.conv_blocks.{i_level}.res.{j}", block_in, block_out))
+            block_in = block_out
+            if i_level == nres - 1:
+                out.append(("attn", f"encoder.conv_blocks.{i_level}.attn.{j}", block_in))
+        if i_level != nres - 1:
+            out.append(("down", f"encoder.conv_blocks.{i_level}.downsample", block_in))
+    out += [("res", "encoder.mid.0", block_in, block_in), ("attn", "encoder.mid.1", block_in), ("res", "encoder.mid.2", block_in, block_in)]
+    return out, block_in
+
+
 def vq_state_dict(cfg: VQConfig, seed: int = 2) -> Dict[str, torch.Tensor]:
     """Decode-side names of VQModel.state_dict() (reference vq_model.py:28-39,129-169)."""
     r = _Rng(seed)
@@ -196,6 +217,30 @@ def vq_state_dict(cfg: VQConfig, seed: int = 2) -> Dict[str, torch.Tensor]:
             _conv(r, sd, name + ".conv", c, c, 3)
     _gn(r, sd, "decoder.norm_out", last)
     _conv(r, sd, "decoder.conv_out", 3, last, 3)
+    # ---- encode side (vq_model.py:62-126 Encoder, :39 quant_conv).  Appended AFTER the decode side so the decoder tensors
+    # (and every golden minted from them) keep their values.
+    enc, elast = vq_encoder_layout(cfg)
+    _conv(r, sd, "encoder.conv_in", cfg.ch, 3, 3)
+    for item in enc:
+        if item[0] == "res":
+            _, name, cin, cout = item
+            _gn(r, sd, name + ".norm1", cin)
+            _conv(r, sd, name + ".conv1", cout, cin, 3)
+            _gn(r, sd, name + ".norm2", cout)
+            _conv(r, sd, name + ".conv2", cout, cout, 3)
+            if cin != cout:
+                _conv(r, sd, name + ".nin_shortcut", cout, cin, 1)
+        elif item[0] == "attn":
+            _, name, c = item
+            _gn(r, sd, name + ".norm", c)
+            for n in ("q", "k", "v", "proj_out"):
+                _conv(r, sd, f"{name}.{n}", c, c, 1)
+        else:
+            _, name, c = item
+            _conv(r, sd, name + ".conv", c, c, 3)
+    _gn(r, sd, "encoder.norm_out", elast)
+    _conv(r, sd, "encoder.conv_out", cfg.z_channels, elast, 3)
+    _conv(r, sd, "quant_conv", cfg.codebook_embed_dim, cfg.z_channels, 1)
     return sd
 
 

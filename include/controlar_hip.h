@@ -150,6 +150,13 @@ int car_sample_logits(car_ctx* ctx, const float* logits, int32_t B, int32_t V, c
  */
 int car_vq_decode(car_ctx* ctx, const int32_t* tokens, int32_t B, int32_t h, int32_t w, float* out_nchw, void* stream);
 
+/*
+ * VQModel.encode(x)[2][2] — tokenizer/tokenizer_image/vq_model.py:41-46 (Encoder :62-126, quant_conv :39, VectorQuantizer
+ * arg-min :216-232): image fp32 NCHW [B,3,H,W] in [-1,1] -> min_encoding_indices int32 [B,(H/16)(W/16)] (device).
+ * Needs the `encoder.*` and `quant_conv.*` tensors (the step on the other side of the tokenizer).
+ */
+int car_vq_encode(car_ctx* ctx, const float* img_nchw, int32_t B, int32_t H, int32_t W, int32_t* out_tokens, void* stream);
+
 /* Introspection used by tests and bench.py */
 typedef struct car_stats {
     double  decode_ms;          /* HIP-event time of the last car_generate's decode loop (n_new-1 steps) */

@@ -463,3 +463,46 @@ def vq_decode_code(sd, cfg, codes: Tensor, shape) -> Tensor:
             x = _conv(x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3), sd, item[1] + ".conv", 1)
     x = _gn_swish(x, sd, "decoder.norm_out", cfg)
     return _conv(x, sd, "decoder.conv_out", 1)
+
+
+# --------------------------------------------------------------------------------------
+# VQGAN encoder + quantizer ("next" row §8f-4)   (reference: vq_model.py:41-46 encode, :62-126 Encoder, :216-246 quantizer)
+# --------------------------------------------------------------------------------------
+def _encoder_layout(cfg):
+    nres = len(cfg.ch_mult)
+    in_mult = (1,) + tuple(cfg.ch_mult)
+    out = []
+    block_in = cfg.ch
+    for i_level in range(nres):
+        block_in = cfg.ch * in_mult[i_level]
+        block_out = cfg.ch * cfg.ch_mult[i_level]
+        for j in range(cfg.num_res_blocks):
+            out.append(("res", f"encoder.conv_blocks.{i_level}.res.{j}", block_in, block_out))
+            block_in = block_out
+            if i_level == nres - 1:
+                out.append(("attn", f"encoder.conv_blocks.{i_level}.attn.{j}", block_in))
+        if i_level != nres - 1:
+            out.append(("down", f"encoder.conv_blocks.{i_level}.downsample", block_in))
+    out += [("res", "encoder.mid.0", block_in, block_in), ("attn", "encoder.mid.1", block_in), ("res", "encoder.mid.2", block_in, block_in)]
+    return out
+
+
+def vq_encode(sd, cfg, img: Tensor):
+    """VQModel.encode -> min_encoding_indices [B, h*w] (int64) and the pre-quantisation z [B, cd, h, w].
+    Encoder.forward (:107-126); Downsample = F.pad (0,1,0,1) + conv3x3 stride 2 (:382-396); quant_conv (:39,:44);
+    VectorQuantizer.forward (:216-232): l2-normalise z and codebook, d = |z|^2 + |e|^2 - 2 z.e, argmin (first minimum)."""
+    x = _conv(img.float(), sd, "encoder.conv_in", 1)
+    for item in _encoder_layout(cfg):
+        if item[0] == "res":
+            x = _resblock(x, sd, item[1], item[2], item[3], cfg)
+        elif item[0] == "attn":
+            x = _attnblock(x, sd, item[1], cfg)
+        else:
+            x = F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[item[1] + ".conv.weight"], sd[item[1] + ".conv.bias"], stride=2)
+    x = _conv(_gn_swish(x, sd, "encoder.norm_out", cfg), sd, "encoder.conv_out", 1)
+    z = _conv(x, sd, "quant_conv", 0)
+    B, C, h, w = z.shape
+    zf = F.normalize(z.permute(0, 2, 3, 1).reshape(-1, C), p=2, dim=-1)
+    emb = F.normalize(sd["quantize.embedding.weight"].float(), p=2, dim=-1)
+    d = torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(emb ** 2, dim=1) - 2 * (zf @ emb.t())
+    return torch.argmin(d, dim=1).view(B, h * w), z

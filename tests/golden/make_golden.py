@@ -298,6 +298,32 @@ CASES["tiny_c2i_cfg1"] = case_c2i_tiny
 CASES["b_c2i_canny_fixtures_cfg1"] = case_c2i_b
 
 
+
+
+def case_vq_encode(name, cfg, H, W, seed=2):
+    """VQModel.encode (Encoder + quant_conv + quantizer arg-min) of the reference on a smooth synthetic image."""
+    sd = synth.vq_state_dict(cfg, seed=seed)
+    m = ref_vq.VQModel(ref_vq.ModelArgs(codebook_size=cfg.codebook_size, codebook_embed_dim=cfg.codebook_embed_dim,
+                                        encoder_ch_mult=list(cfg.ch_mult), decoder_ch_mult=list(cfg.ch_mult), z_channels=cfg.z_channels))
+    if cfg.ch != 128:
+        m.decoder = ref_vq.Decoder(ch_mult=list(cfg.ch_mult), z_channels=cfg.z_channels, ch=cfg.ch, num_res_blocks=cfg.num_res_blocks)
+        m.encoder = ref_vq.Encoder(ch_mult=list(cfg.ch_mult), z_channels=cfg.z_channels, ch=cfg.ch, num_res_blocks=cfg.num_res_blocks)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert all(k.startswith("quantize.codebook_used") for k in missing), missing
+    assert not unexpected, unexpected
+    m.eval()
+    img = synth.smooth_control(2, H, W, seed=77) + 0.1 * synth.canny_like_control(2, H, W, seed=78)
+    with torch.no_grad():
+        quant, _, info = m.encode(img)
+    idx = info[2].view(2, -1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), tokens=idx.numpy().astype(np.int32), meta=np.array([2, H, W, seed], dtype=np.int64))
+    print(name, idx.shape, "distinct", len(np.unique(idx.numpy())))
+
+
+CASES["vq_encode_tiny"] = lambda: case_vq_encode("vq_encode_tiny", C.tiny_t2i().vq, 128, 128)
+CASES["vq_encode_vq16_64x64"] = lambda: case_vq_encode("vq_encode_vq16_64x64", C.VQConfig(), 64, 64)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or DEFAULT
     for n in names:

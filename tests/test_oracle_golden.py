@@ -106,3 +106,13 @@ def test_oracle_c2i_tracks_reference_bf16(name, mk, golden_dir):
         assert d.max() < 0.8 and d.mean() < 0.08, (dtype, d.max(), d.mean())
         agree = toks.numpy() == gold["tokens"]
         assert agree[gold["margin"] > 0.5].all() and agree.mean() > 0.9, (dtype, agree.mean())
+
+
+@pytest.mark.parametrize("name,mk,hw", [("vq_encode_tiny", lambda: C.tiny_t2i().vq, 128), ("vq_encode_vq16_64x64", lambda: C.VQConfig(), 64)])
+def test_oracle_vq_encode_matches_reference(name, mk, hw, golden_dir):
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = mk()
+    sd = synth.vq_state_dict(cfg, seed=int(gold["meta"][3]))
+    img = synth.smooth_control(2, hw, hw, seed=77) + 0.1 * synth.canny_like_control(2, hw, hw, seed=78)
+    idx, _ = O.vq_encode(sd, cfg, img)
+    assert np.array_equal(idx.numpy(), gold["tokens"])

@@ -379,3 +379,30 @@ def test_fp8_weight_decode_config5():
     with pytest.raises(RuntimeError):
         Engine(cfg, "fp32", weights_fp8=True)      # fp8 weights exist only in the fast mode
     eng.close()
+
+
+@pytest.mark.parametrize("name,mk,hw", [("vq_encode_tiny", "tiny", 128), ("vq_encode_vq16_64x64", "vq16", 64)])
+def test_vq_encode_tokens(name, mk, hw):
+    """VQModel.encode: encoder + quant_conv + quantizer arg-min.  Exact mode reproduces the reference's
+    min_encoding_indices bit-for-bit; bf16 mode must agree on the large majority (arg-min over 16384 near-equidistant codes)."""
+    import os
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    from tests.cases import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = C.tiny_t2i(64, "canny")
+    if mk == "vq16":
+        cfg.vq = C.VQConfig()
+    vsd = synth.vq_state_dict(cfg.vq, seed=int(gold["meta"][3]))
+    img = synth.smooth_control(2, hw, hw, seed=77) + 0.1 * synth.canny_like_control(2, hw, hw, seed=78)
+    for prec in ("fp32", "bf16"):
+        eng = Engine(cfg, prec); eng.load_state_dict(vsd, finalize=True)
+        toks = eng.vq_encode(img.cuda()).cpu().numpy()
+        if prec == "fp32":
+            assert np.array_equal(toks, gold["tokens"]), (toks != gold["tokens"]).sum()
+            # encode -> decode round trip stays finite and in range
+            px = eng.vq_decode(torch.from_numpy(toks), hw // 16, hw // 16)
+            assert bool(torch.isfinite(px).all())
+        else:
+            assert (toks == gold["tokens"]).mean() >= 0.6, (toks == gold["tokens"]).mean()
+        eng.close()
