@@ -898,9 +898,11 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     // reference layout [cond 0..B-1 | uncond 0..B-1] (generate.py:158-163).
     const bool fast = mode == CAR_BF16;
     const int mult = use_cfg ? 2 : 1;
-    int NG = (fast && b >= 32) ? (b <= 64 ? 2 : (b + 63) / 64) : 1;      // chains of <= 64 rows (the dec_linear<4> sweet spot)
+    // chains of <= 64 rows (the dec_linear<4> sweet spot); measured on MI355X (XL, tools/decode_probe.py): one chain wins up to
+    // b = 32 (2.55 vs 2.67 ms/step), break-even at 48, two chains win from 64 (3.09 vs 3.14) and clearly at 96 (3.79 vs 4.32)
+    int NG = (fast && b >= 48) ? (b <= 64 ? 2 : (b + 63) / 64) : 1;
     if (NG > 8) NG = 8;
-    if (NG > 1) { const char* ev = getenv("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 8 && B / v >= 4) NG = v; } }
+    if (fast) { const char* ev = getenv("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 8 && B / v >= 2) NG = v; } }
     if (getenv("CAR_SINGLE_CHAIN") || NG > B) NG = 1;
     int img0[9];
     for (int gi = 0; gi <= NG; ++gi) img0[gi] = (int)((long)B * gi / NG);

@@ -158,9 +158,6 @@ class VQModel:
         return self.engine.vq_encode(x)
 
 
-VQModel.encode_indices = encode_indices
-del encode_indices
-
 
 def VQ_16(**kw):
     return VQModel(VQConfig(ch_mult=(1, 1, 2, 2, 4), **kw))

@@ -72,3 +72,15 @@ def test_e4m3_conversion_matches_torch():
     got_f = torch.from_numpy(out).view(torch.float8_e4m3fn).float()
     want_f = torch.from_numpy(want).view(torch.float8_e4m3fn).float()
     assert torch.equal(got_f, want_f)
+
+
+def test_dropin_modules_import_and_factories_build_without_gpu():
+    """controlar_amd.models / generate import cleanly and the reference-shaped factories build (weights/contexts are lazy)."""
+    from controlar_amd import generate as G, models as M
+    gpt = M.GPT_models["GPT-XL"](block_size=1024, cls_token_num=120, model_type="t2i", condition_type="canny", adapter_size="small")
+    assert gpt.model_type == "t2i" and gpt.cfg.gpt.dim == 1280 and gpt.cfg.vit.hidden == 384
+    c2i = M.GPT_models["GPT-B"](vocab_size=16384, block_size=256, num_classes=1000, cls_token_num=1, model_type="c2i",
+                                condition_token_num=0, image_size=256)
+    assert c2i.cfg.vit.variant == "vit" and c2i.cfg.vit.patch == 16
+    vq = M.VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8)
+    assert hasattr(vq, "decode_code") and hasattr(vq, "encode_indices") and callable(G.generate)
