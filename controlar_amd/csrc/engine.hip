@@ -73,12 +73,14 @@ void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const f
 
 static thread_local std::string g_create_err;
 
+static unsigned long long g_alloc_gen = 0;     // bumped on every (re)allocation: captured graphs bake raw pointers, so their cache key includes it
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     bool ensure(size_t bytes) {
         if (bytes <= cap) return true;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
+        ++g_alloc_gen;
         size_t want = bytes + (bytes >> 3) + 256;
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
         cap = want; return true;
@@ -1108,7 +1110,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         char keyb[512];
         snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%p|%p", b, B, S_max, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval * 4 + NG, (const void*)forced_tokens, (void*)logits_out);
-        { char kb2[160]; snprintf(kb2, sizeof(kb2), "|%d|%g|%d|%g|%llu", sp->sample_logits, (double)sp->temperature, sp->top_k, (double)sp->top_p, (unsigned long long)sp->seed); strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
+        { char kb2[200]; snprintf(kb2, sizeof(kb2), "|%d|%g|%d|%g|%llu|gen%llu|%p|%p|%p", sp->sample_logits, (double)sp->temperature, sp->top_k, (double)sp->top_p,
+                                   (unsigned long long)sp->seed, g_alloc_gen, xn, att, mid); strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
         bool graph_ok = true;
         if (getenv("CAR_NO_GRAPH")) { /* skip capture */ }

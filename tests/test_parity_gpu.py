@@ -106,6 +106,12 @@ def test_generate_is_deterministic_and_repeatable():
         outs.append(eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), cfg_scale=cs["cfg_scale"],
                                  control_strength=cs["control_strength"]).cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    # a VQ decode in the SAME context re-sizes shared workspaces: the cached decode graph must not be replayed with stale pointers
+    px = eng.vq_decode(outs[0], cs["H"] // 16, cs["W"] // 16)
+    big = eng.vq_decode(outs[0].repeat(8, 1), cs["H"] // 16, cs["W"] // 16)
+    assert bool(torch.isfinite(px).all()) and bool(torch.isfinite(big).all())
+    again = eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"]).cpu()
+    assert torch.equal(again, outs[0])
     # shorter request after a longer one (KV/graph re-sizing path, BASELINE config 4)
     short = eng.generate(cs["emb"].cuda(), 16, cs["mask"].cuda(), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"]).cpu()
     assert torch.equal(short, outs[0][:, :16])
