@@ -92,11 +92,13 @@ int  car_abi_version(void);
 
 /*
  * Weight loading — keyed by the reference state_dict names (SURVEY.md §8b "Weight contract"):
- * gpt_t2i.Transformer names (incl. HF Dinov2 under "adapter.model.") and VQModel names.
+ * gpt_t2i.Transformer / gpt.Transformer names (incl. HF Dinov2 / ViT under "adapter.model.", 4.x and 5.x key spellings)
+ * and VQModel names (decoder.*, post_quant_conv.*, quantize.embedding.weight; encoder.* + quant_conv.* enable car_vq_encode).
  * `ptr` may be a host or device pointer; dtype CAR_DT_F32 or CAR_DT_BF16; shape row-major.
- * Unknown names return 0 and are ignored when they are reference tensors unused at inference
- * (condition_embeddings.weight, *.mask_token, encoder.*, quant_conv.*), non-zero otherwise.
- * car_finalize_weights checks that every tensor the path needs has arrived and packs them.
+ * Reference tensors that inference never reads (condition_embeddings.weight, *.mask_token, pooler.*, condition_norm.weight,
+ * quantize.codebook_used) are accepted and ignored.  Tensors are packed as they arrive (MFMA-fragment images of the decode
+ * linears, w1|w3 interleave, implicit-GEMM conv layouts, optional e4m3 quantisation);
+ * car_finalize_weights checks that every tensor the loaded model halves need has arrived.
  */
 int car_load_tensor(car_ctx* ctx, const char* name, const void* ptr, const int64_t* shape, int32_t ndim, int32_t dtype);
 int car_finalize_weights(car_ctx* ctx);
@@ -113,9 +115,9 @@ int car_encode_control(car_ctx* ctx, const void* img, int32_t img_dtype, int32_t
 /*
  * generate() — replaces autoregressive/models/generate.py:134-204 (t2i branch).
  *   text_emb  [B,T,caption_dim] (F32/BF16 per text_dtype), emb_mask [B,T] int64 (may be NULL),
- *   n_new     = max_new_tokens, grid_w = token-grid width of the image (W/16), used only for shape
- *               checks (RoPE is indexed linearly as the reference does, gpt_t2i.py:454),
- *   use_control != 0 consumes the control tokens of the preceding car_encode_control (same B),
+ *   n_new     = max_new_tokens <= block_size (RoPE is indexed linearly on the sqrt(block_size)-wide grid exactly as the
+ *               reference does, gpt_t2i.py:454 — also for non-square token grids, sample_t2i_MR.py:73-78,182-185),
+ *   use_control != 0 consumes the control tokens of the preceding car_encode_control (same B, >= n_new tokens),
  *   out_tokens [B,n_new] int32 (device).
  * Debug/teacher-forcing extras (tests): forced_tokens [B,n_new] int32 or NULL
  * (token fed back at step i is forced[i]); logits_out [B,n_new,vocab] fp32 or NULL (post-CFG logits
