@@ -172,30 +172,25 @@ def main():
             px = vq_eng.vq_decode(toks, gh, gw)     # enqueued asynchronously; the next step's generate() does not wait for it
         return toks, px
 
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()   # waits for the side stream too
-    log("warmup done")
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    dec_ms, pre_ms = 0.0, 0.0
-    st = None
-    for _ in range(args.steps):
+    acc = {"dec_ms": 0.0, "pre_ms": 0.0, "st": None, "warm": True}
+
+    def step_and_stats():
         toks, px = one_step()
-        st = eng.stats()                                    # waits on the library's own stream events
-        dec_ms += st["decode_ms"]; pre_ms += st["prefill_ms"]
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        st_ = eng.stats()                                   # waits on the library's own stream events (HIP-event timed decode loop)
+        if not acc["warm"]:
+            acc["dec_ms"] += st_["decode_ms"]; acc["pre_ms"] += st_["prefill_ms"]
+        acc["st"] = st_
+        return toks, px
+
+    from controlar_amd.dist import timed_steps
+    # warmup runs through the same harness with zero timed steps so that the accumulators only see the timed region
+    timed_steps(dist, dev, step_and_stats, 0, args.warmup, torch.cuda.synchronize)
+    log("warmup done")
+    acc["warm"] = False
+    elapsed, (toks, px) = timed_steps(dist, dev, step_and_stats, args.steps, 0, torch.cuda.synchronize)
+    dec_ms, pre_ms, st = acc["dec_ms"], acc["pre_ms"], acc["st"]
     log(f"timed region {elapsed:.2f}s")
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
         all_toks = gather_tokens(dist, toks)                # [G, n_new] on every rank
         assert all_toks.shape[0] == G
     assert bool(torch.isfinite(px).all())
@@ -210,7 +205,7 @@ def main():
     def pmc_traffic_per_step(b, kv_bytes_per_step):
         if args.model != "xl" or args.precision != "bf16":
             return None
-        chains = 1 if b < 32 else min(8, max(2, (b + 63) // 64)) if args.cfg_scale <= 1.0 else 1
+        chains = 1 if b < 48 else (2 if b <= 64 else min(8, (b + 63) // 64))       # engine.hip generate_impl: chains of <= 64 rows
         per_chain = (36 * 64.55e6 + 4.25e6 + 43.4e6 + 16.8e6) * (min(b / chains, 64) / 64 * 0.37 + 0.63)   # partial traffic scales with rows, weights do not
         return chains * per_chain + 1.04 * kv_bytes_per_step
 

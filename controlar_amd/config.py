@@ -136,6 +136,13 @@ def tiny_c2i(block_size: int = 64, vocab_size: int = 1024, num_classes: int = 10
     )
 
 
+def tiny_t2i_base(block_size: int = 64, condition_type: str = "hed", vocab_size: int = 1024) -> PathConfig:
+    """tiny_t2i with a 'base'-shaped control encoder (3 heads x 64, like DINOv2-base's 12 x 64) and a bicubic condition type."""
+    cfg = tiny_t2i(block_size, condition_type, vocab_size)
+    cfg.vit = ViTConfig(hidden=192, layers=3, heads=3)
+    return cfg
+
+
 def tiny_t2i(block_size: int = 64, condition_type: str = "canny", vocab_size: int = 1024) -> PathConfig:
     """Small parity-test configuration: same graph, every dimension shrunk so the CPU oracle
     (and the imported reference) finish in seconds.  head_dim stays 64 as in every LlamaGen size."""

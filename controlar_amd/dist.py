@@ -47,3 +47,32 @@ def gather_tokens(dist, local_tokens: torch.Tensor) -> torch.Tensor:
     dist.all_gather(parts, local_tokens.contiguous())
     out = torch.stack(parts, dim=1)                       # [per_rank, world, N]: image r + W*i lives at [i, r]
     return out.reshape(-1, local_tokens.shape[-1])
+
+
+def timed_steps(dist, device, step_fn, steps: int, warmup: int, sync_fn=None):
+    """The bench contract's timing harness: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier and a
+    device synchronise on both sides; returns (elapsed seconds as the MAX over ranks, last step's return value).
+    `sync_fn` = torch.cuda.synchronize on GPU ranks, None on CPU (gloo tests)."""
+    import time
+    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    sync = sync_fn if sync_fn is not None else (lambda: None)
+    out = None
+    for _ in range(warmup):
+        out = step_fn()
+    sync()
+    if multi:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step_fn()
+    sync()
+    if multi:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out

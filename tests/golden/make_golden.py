@@ -169,6 +169,9 @@ CASES = {
     # the reference's own bf16 default, for tolerance calibration of the fast mode
     "tiny_canny_cfg1_bf16": lambda: run_case("tiny_canny_cfg1_bf16", C.tiny_t2i(64, "canny"), 2, 128, 128, 1.0,
                                              dtype=torch.bfloat16, vq=False),
+    # 'base'-shaped encoder (heads x 64), bicubic resize, CFG + control_strength
+    "tiny_hed_base_cfg1p5": lambda: run_case("tiny_hed_base_cfg1p5", C.tiny_t2i_base(64, "hed"), 2, 128, 128, 1.5,
+                                             control_strength=0.6, control="smooth", vq=False),
     "vq16_real_8x8": case_vq16_real,
     # GPT-B sized, 256 tokens
     "b_canny_256_cfg4": lambda: run_case("b_canny_256_cfg4", C.b_t2i(256, "small", "canny"), 1, 256, 256, 4.0,

@@ -60,3 +60,39 @@ def test_shard_helpers():
     got = sorted(sum([idx[shard_slice(10, 4, r)] for r in range(4)], []))
     assert got == idx
     assert pad_to_world(10, 4) == 12 and pad_to_world(8, 4) == 8
+
+
+def _timed_worker(rank, world, port, q):
+    import time
+    import torch.distributed as dist
+    from controlar_amd.dist import timed_steps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def step():
+        calls.append(time.perf_counter())
+        time.sleep(0.05 * (rank + 1))          # rank 1 is the slow one
+        return rank, len(calls)
+
+    elapsed, out = timed_steps(dist, torch.device("cpu"), step, steps=3, warmup=2, sync_fn=None)
+    q.put((rank, elapsed, out, len(calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_timed_steps_contract_world2():
+    """bench.py's harness: W untimed + exactly K timed steps, barrier-bracketed, elapsed = MAX over ranks."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_timed_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (r0, e0, out0, n0), (r1, e1, out1, n1) = res
+    assert n0 == 5 and n1 == 5 and out0 == (0, 5) and out1 == (1, 5)      # 2 warm-up + 3 timed calls each
+    assert abs(e0 - e1) < 1e-9                                              # both ranks report the same (max) time
+    assert 0.29 <= e0 <= 0.6                                                # = 3 x 0.10 s of the slow rank, not 3 x 0.05

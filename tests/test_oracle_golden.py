@@ -15,6 +15,7 @@ CASES = {
     "tiny_mr_192x128": (lambda: C.tiny_t2i(144, "canny"), "canny", torch.float32),
     "tiny_mr_128x192": (lambda: C.tiny_t2i(144, "canny"), "canny", torch.float32),
     "tiny_cfg_interval": (lambda: C.tiny_t2i(64, "canny"), "canny", torch.float32),
+    "tiny_hed_base_cfg1p5": (lambda: C.tiny_t2i_base(64, "hed"), "smooth", torch.float32),
 }
 
 
