@@ -279,6 +279,19 @@ def class_labels(batch: int, num_classes: int, seed: int = 1234) -> torch.Tensor
     return torch.randint(0, num_classes, (batch,), generator=g, dtype=torch.int64)
 
 
+def text_embeddings_with_lengths(lengths, T: int = 120, caption_dim: int = 2048, seed: int = 1234):
+    """As text_embeddings but with explicit valid lengths (edge cases: 1 = a single real token, T = no padding at all)."""
+    embs, masks = [], []
+    for i, L in enumerate(lengths):
+        g = torch.Generator().manual_seed(seed + i)
+        e = 0.2 * torch.randn(T, caption_dim, generator=g)
+        m = torch.zeros(T, dtype=torch.int64)
+        m[T - int(L):] = 1
+        embs.append(e * m[:, None])
+        masks.append(m)
+    return torch.stack(embs), torch.stack(masks)
+
+
 def text_embeddings(batch: int, T: int = 120, caption_dim: int = 2048, seed: int = 1234):
     """0.2*randn caption features, valid length L~U{8..40}, LEFT-padded exactly as
     sample_t2i.py:146-160: valid tokens occupy the last L slots, features multiplied by mask."""

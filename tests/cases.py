@@ -16,6 +16,8 @@ CASES = {
     "tiny_mr_128x192": (lambda: C.tiny_t2i(144, "canny"), "canny", -1),
     "tiny_cfg_interval": (lambda: C.tiny_t2i(64, "canny"), "canny", 20),
     "tiny_hed_base_cfg1p5": (lambda: C.tiny_t2i_base(64, "hed"), "smooth", -1),
+    "tiny_mask_edges": (lambda: C.tiny_t2i(64, "canny"), "canny", -1),
+    "tiny_no_mask": (lambda: C.tiny_t2i(64, "canny"), "canny", -1),
 }
 
 
@@ -26,6 +28,10 @@ def load_case(name):
     B, H, W, seed, _threads = [int(x) for x in gold["meta"]]
     img = synth.canny_like_control(B, H, W) if control == "canny" else synth.smooth_control(B, H, W)
     emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    if name == "tiny_mask_edges":       # one real token | no padding | typical
+        emb, mask = synth.text_embeddings_with_lengths([1, 120, 40], cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    elif name == "tiny_no_mask":        # generate(..., emb_masks=None): plain causal mask (generate.py:184)
+        mask = None
     gsd, vsd = synth.path_state_dicts(cfg, seed=seed)
     return dict(cfg=cfg, gold=gold, B=B, H=H, W=W, img=img, emb=emb, mask=mask, gsd=gsd, vsd=vsd,
                 cfg_scale=float(gold["cfg_scale"]), control_strength=float(gold["control_strength"]),

@@ -98,14 +98,17 @@ class _Tap:
 
 
 def run_case(name, cfg: C.PathConfig, B, H, W, cfg_scale, control_strength=1.0, dtype=torch.float32,
-             control="canny", seed=0, threads=8, vq=True, keep_logits="all", cfg_interval=-1):
+             control="canny", seed=0, threads=8, vq=True, keep_logits="all", cfg_interval=-1, lengths=None, no_mask=False):
     torch.set_num_threads(threads)
     t0 = time.time()
     gsd, vsd = synth.path_state_dicts(cfg, seed=seed)
     model = build_ref_gpt(cfg, gsd, dtype)
     g = cfg.gpt
     img = (synth.canny_like_control(B, H, W) if control == "canny" else synth.smooth_control(B, H, W))
-    emb, mask = synth.text_embeddings(B, g.cls_token_num, g.caption_dim)
+    emb, mask = (synth.text_embeddings(B, g.cls_token_num, g.caption_dim) if lengths is None
+                 else synth.text_embeddings_with_lengths(lengths, g.cls_token_num, g.caption_dim))
+    if no_mask:
+        mask = None
     n_new = (H // 16) * (W // 16)
     with torch.no_grad():
         ad = model.adapter(img.to(dtype))
@@ -172,6 +175,9 @@ CASES = {
     # 'base'-shaped encoder (heads x 64), bicubic resize, CFG + control_strength
     "tiny_hed_base_cfg1p5": lambda: run_case("tiny_hed_base_cfg1p5", C.tiny_t2i_base(64, "hed"), 2, 128, 128, 1.5,
                                              control_strength=0.6, control="smooth", vq=False),
+    # ragged / extreme text-pad masks: one real token, no padding at all, typical; and emb_masks=None
+    "tiny_mask_edges": lambda: run_case("tiny_mask_edges", C.tiny_t2i(64, "canny"), 3, 128, 128, 1.5, vq=False, lengths=[1, 120, 40]),
+    "tiny_no_mask": lambda: run_case("tiny_no_mask", C.tiny_t2i(64, "canny"), 2, 128, 128, 1.0, vq=False, no_mask=True),
     "vq16_real_8x8": case_vq16_real,
     # GPT-B sized, 256 tokens
     "b_canny_256_cfg4": lambda: run_case("b_canny_256_cfg4", C.b_t2i(256, "small", "canny"), 1, 256, 256, 4.0,

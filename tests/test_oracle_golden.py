@@ -16,6 +16,8 @@ CASES = {
     "tiny_mr_128x192": (lambda: C.tiny_t2i(144, "canny"), "canny", torch.float32),
     "tiny_cfg_interval": (lambda: C.tiny_t2i(64, "canny"), "canny", torch.float32),
     "tiny_hed_base_cfg1p5": (lambda: C.tiny_t2i_base(64, "hed"), "smooth", torch.float32),
+    "tiny_mask_edges": (lambda: C.tiny_t2i(64, "canny"), "canny", torch.float32),
+    "tiny_no_mask": (lambda: C.tiny_t2i(64, "canny"), "canny", torch.float32),
 }
 
 
@@ -26,12 +28,21 @@ def _inputs(cfg, gold, control):
     return B, H, W, seed, img, emb, mask
 
 
+def _edge_inputs(name, cfg, emb, mask):
+    if name == "tiny_mask_edges":
+        return synth.text_embeddings_with_lengths([1, 120, 40], cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    if name == "tiny_no_mask":
+        return emb, None
+    return emb, mask
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_oracle_matches_reference_fp32(name, golden_dir):
     mk, control, dtype = CASES[name]
     cfg = mk()
     gold = np.load(os.path.join(golden_dir, name + ".npz"))
     B, H, W, seed, img, emb, mask = _inputs(cfg, gold, control)
+    emb, mask = _edge_inputs(name, cfg, emb, mask)
     gsd, vsd = synth.path_state_dicts(cfg, seed=seed)
     n_new = (H // 16) * (W // 16)
     interval = 20 if name == "tiny_cfg_interval" else -1

@@ -18,6 +18,10 @@ from tests.cases import CASES, load_case
 pytestmark = pytest.mark.gpu
 
 
+def _mask(cs):
+    return cs["mask"].cuda() if cs["mask"] is not None else None
+
+
 def _engine(cs, prec):
     from controlar_amd.engine import Engine
     eng = Engine(cs["cfg"], prec)
@@ -31,7 +35,7 @@ def test_exact_mode_tokens_bit_identical(name):
     cs = load_case(name); gold = cs["gold"]
     eng = _engine(cs, "fp32")
     a = eng.encode_control(cs["img"].cuda(), want_output=True).cpu()
-    toks, logits = eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), cfg_scale=cs["cfg_scale"],
+    toks, logits = eng.generate(cs["emb"].cuda(), cs["n_new"], _mask(cs), cfg_scale=cs["cfg_scale"],
                                 cfg_interval=cs["cfg_interval"], control_strength=cs["control_strength"], return_logits=True)
     np.testing.assert_allclose(a.numpy()[:, ::7, ::5], gold["adapter_mlp_out"], atol=5e-5, rtol=1e-4)
     assert np.array_equal(toks.cpu().numpy(), gold["tokens"])
@@ -58,7 +62,7 @@ def test_fast_mode_teacher_forced(name):
     eng = _engine(cs, "bf16")
     eng.encode_control(cs["img"].cuda())
     forced = torch.from_numpy(gold["tokens"])
-    toks, logits = eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), cfg_scale=cs["cfg_scale"],
+    toks, logits = eng.generate(cs["emb"].cuda(), cs["n_new"], _mask(cs), cfg_scale=cs["cfg_scale"],
                                 cfg_interval=cs["cfg_interval"], control_strength=cs["control_strength"],
                                 forced_tokens=forced, return_logits=True)
     d = np.abs(logits.cpu().numpy() - gold["logits"])
@@ -103,17 +107,17 @@ def test_generate_is_deterministic_and_repeatable():
     outs = []
     for _ in range(3):
         eng.encode_control(cs["img"].cuda())
-        outs.append(eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), cfg_scale=cs["cfg_scale"],
+        outs.append(eng.generate(cs["emb"].cuda(), cs["n_new"], _mask(cs), cfg_scale=cs["cfg_scale"],
                                  control_strength=cs["control_strength"]).cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     # a VQ decode in the SAME context re-sizes shared workspaces: the cached decode graph must not be replayed with stale pointers
     px = eng.vq_decode(outs[0], cs["H"] // 16, cs["W"] // 16)
     big = eng.vq_decode(outs[0].repeat(8, 1), cs["H"] // 16, cs["W"] // 16)
     assert bool(torch.isfinite(px).all()) and bool(torch.isfinite(big).all())
-    again = eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"]).cpu()
+    again = eng.generate(cs["emb"].cuda(), cs["n_new"], _mask(cs), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"]).cpu()
     assert torch.equal(again, outs[0])
     # shorter request after a longer one (KV/graph re-sizing path, BASELINE config 4)
-    short = eng.generate(cs["emb"].cuda(), 16, cs["mask"].cuda(), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"]).cpu()
+    short = eng.generate(cs["emb"].cuda(), 16, _mask(cs), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"]).cpu()
     assert torch.equal(short, outs[0][:, :16])
     eng.close()
 
@@ -123,16 +127,16 @@ def test_error_paths_raise():
     from controlar_amd.engine import Engine
     eng = Engine(cs["cfg"], "bf16")
     with pytest.raises(RuntimeError):
-        eng.generate(cs["emb"].cuda(), 8, cs["mask"].cuda())            # weights not finalized
+        eng.generate(cs["emb"].cuda(), 8, _mask(cs))            # weights not finalized
     eng.load_state_dict(cs["gsd"])
     eng.finalize()
     with pytest.raises(RuntimeError):
-        eng.generate(cs["emb"].cuda(), 8, cs["mask"].cuda())            # control tokens not encoded for this batch
+        eng.generate(cs["emb"].cuda(), 8, _mask(cs))            # control tokens not encoded for this batch
     with pytest.raises(RuntimeError):
         eng.vq_decode(torch.zeros(1, 64, dtype=torch.int32), 8, 8)       # VQ weights not loaded
     eng.encode_control(cs["img"].cuda())
     with pytest.raises(RuntimeError):
-        eng.generate(cs["emb"].cuda(), 4096, cs["mask"].cuda())          # beyond block_size
+        eng.generate(cs["emb"].cuda(), 4096, _mask(cs))          # beyond block_size
     eng.close()
 
 
@@ -172,23 +176,23 @@ def test_dropin_api_matches_reference_signatures():
     gpt = Transformer(cfg.gpt, cfg.vit).to("cuda", dtype=torch.float32)
     gpt.load_state_dict(cs["gsd"], strict=False); gpt.eval()
     vq = VQModel(cfg.vq); vq.to("cuda"); vq.eval(); vq.load_state_dict(cs["vsd"])
-    toks = generate(gpt, cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"],
+    toks = generate(gpt, cs["emb"].cuda(), cs["n_new"], _mask(cs), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"],
                     temperature=1.0, top_k=0, top_p=1.0, sample_logits=False, control_strength=cs["control_strength"])
     assert toks.dtype == torch.int32 and tuple(toks.shape) == (cs["B"], cs["n_new"])
     assert np.array_equal(toks.cpu().numpy(), gold["tokens"])
     px = vq.decode_code(toks, [cs["B"], cfg.vq.codebook_embed_dim, cs["H"] // 16, cs["W"] // 16])
     np.testing.assert_allclose(px.cpu().numpy(), gold["pixels"], atol=5e-4, rtol=1e-4)
     # the reference's default call style: sample_logits=True, top_k, top_p, temperature (sample_t2i.py:163-170)
-    s1 = generate(gpt, cs["emb"].cuda(), 16, cs["mask"].cuda(), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"], temperature=1.0,
+    s1 = generate(gpt, cs["emb"].cuda(), 16, _mask(cs), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"], temperature=1.0,
                   top_k=200, top_p=0.95, sample_logits=True, seed=5)
-    s2 = generate(gpt, cs["emb"].cuda(), 16, cs["mask"].cuda(), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"], temperature=1.0,
+    s2 = generate(gpt, cs["emb"].cuda(), 16, _mask(cs), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"], temperature=1.0,
                   top_k=200, top_p=0.95, sample_logits=True, seed=5)
-    s3 = generate(gpt, cs["emb"].cuda(), 16, cs["mask"].cuda(), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"], temperature=1.0,
+    s3 = generate(gpt, cs["emb"].cuda(), 16, _mask(cs), condition=cs["img"].cuda(), cfg_scale=cs["cfg_scale"], temperature=1.0,
                   top_k=200, top_p=0.95, sample_logits=True, seed=6)
     assert torch.equal(s1, s2) and not torch.equal(s1, s3)
     assert int(s1.min()) >= 0 and int(s1.max()) < cfg.gpt.vocab_size
     # no control image at all (condition=None) is a legal call of the reference too
-    t0 = generate(gpt, cs["emb"].cuda(), 8, cs["mask"].cuda(), condition=None, cfg_scale=1.0, sample_logits=False)
+    t0 = generate(gpt, cs["emb"].cuda(), 8, _mask(cs), condition=None, cfg_scale=1.0, sample_logits=False)
     assert tuple(t0.shape) == (cs["B"], 8)
 
 
