@@ -64,6 +64,7 @@ SYMBOLS = {
     "car_vq_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "car_vq_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "car_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CarStats)]),
+    "car_debug_pack_decode_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "car_debug_f32_to_e4m3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "car_debug_control_tokens": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
 }

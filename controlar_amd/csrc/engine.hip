@@ -284,17 +284,25 @@ static int upload_packed_fp8(car_ctx* c, const std::string& name, std::vector<fl
 }
 
 // dec_linear weight image: [N/16][K/32] chunks of 64 lanes x 8 bf16 (lane l: row l&15, k (l>>4)*8..+8) — decode.hip
-static int upload_packed(car_ctx* c, const std::string& name, std::vector<float>& h, int N, int K) {
-    if (c->mode != CAR_BF16) return 0;
-    if (c->cfg.decode_weight_fp8) return upload_packed_fp8(c, name, h, N, K);
-    if (N % 16 || K % 32) FAIL(c, "%s: decode packing needs N%%16==0 and K%%32==0 (got %d x %d)", name.c_str(), N, K);
-    std::vector<bf16_t> pk((size_t)N * K);
+static void pack_decode_bf16(const float* h, int N, int K, bf16_t* pk) {
     const int nkb = K / 32;
     for (int rb = 0; rb < N / 16; ++rb) for (int kb = 0; kb < nkb; ++kb) for (int l = 0; l < 64; ++l) {
         const float* src = &h[(size_t)(rb * 16 + (l & 15)) * K + kb * 32 + (l >> 4) * 8];
         bf16_t* dst = &pk[(((size_t)rb * nkb + kb) * 64 + l) * 8];
         for (int e = 0; e < 8; ++e) dst[e] = f2bf(src[e]);
     }
+}
+extern "C" int car_debug_pack_decode_weight(const float* w, int32_t N, int32_t K, uint16_t* out) {      // host-only helper (tests)
+    if (!w || !out || N <= 0 || K <= 0 || N % 16 || K % 32) return -1;
+    pack_decode_bf16(w, N, K, out);
+    return 0;
+}
+static int upload_packed(car_ctx* c, const std::string& name, std::vector<float>& h, int N, int K) {
+    if (c->mode != CAR_BF16) return 0;
+    if (c->cfg.decode_weight_fp8) return upload_packed_fp8(c, name, h, N, K);
+    if (N % 16 || K % 32) FAIL(c, "%s: decode packing needs N%%16==0 and K%%32==0 (got %d x %d)", name.c_str(), N, K);
+    std::vector<bf16_t> pk((size_t)N * K);
+    pack_decode_bf16(h.data(), N, K, pk.data());
     Wt t; t.shape = {N, K}; t.numel = (int64_t)N * K;
     HIPCHK(c, hipMalloc(&t.p, pk.size() * 2));
     HIPCHK(c, hipMemcpy(t.p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));

@@ -171,6 +171,10 @@ typedef struct car_stats {
 } car_stats;
 int car_get_stats(car_ctx* ctx, car_stats* out);
 
+/* Host-only: the MFMA-fragment image of a decode linear W[N,K] (bf16 bits): chunk (rb,kb) = 64 lanes x 8 values, lane l holds
+ * W[16rb + (l&15)][32kb + 8(l>>4) .. +8]; chunks ordered [rb][kb].  N % 16 == 0, K % 32 == 0. */
+int car_debug_pack_decode_weight(const float* w, int32_t N, int32_t K, uint16_t* out);
+
 /* Host-only: fp32 -> OCP e4m3fn bytes with the library's rounding (round-to-nearest-even, saturating at 448). */
 int car_debug_f32_to_e4m3(const float* in, unsigned char* out, int64_t n);
 

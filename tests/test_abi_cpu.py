@@ -84,3 +84,36 @@ def test_dropin_modules_import_and_factories_build_without_gpu():
     assert c2i.cfg.vit.variant == "vit" and c2i.cfg.vit.patch == 16
     vq = M.VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8)
     assert hasattr(vq, "decode_code") and hasattr(vq, "encode_indices") and callable(G.generate)
+
+
+def test_header_is_valid_c99_and_example_compiles():
+    """include/controlar_hip.h must stay a plain C header (extern "C" boundary): gcc -std=c99 syntax-checks the C example."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c_abi_example.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_decode_weight_fragment_packing_layout():
+    """The packed image consumed by dec_linear_kernel: lane l of chunk (rb, kb) holds W[16rb + (l & 15)][32kb + 8(l >> 4) : +8] —
+    exactly the A-operand fragment of v_mfma_f32_16x16x32_bf16, so one 16-byte load per lane feeds one MFMA."""
+    import numpy as np
+    import torch
+    lib = L.load()
+    N, K = 48, 96
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 8.0          # exactly representable in bf16 up to 576
+    w = (w % 251.0).contiguous()
+    out = np.empty(N * K, dtype=np.uint16)
+    assert lib.car_debug_pack_decode_weight(C.c_void_p(w.data_ptr()), N, K, C.c_void_p(out.ctypes.data)) == 0
+    got = torch.from_numpy(out.astype(np.int16)).view(torch.bfloat16).float().reshape(N // 16, K // 32, 64, 8)
+    wb = w.to(torch.bfloat16).float()
+    for rb in range(N // 16):
+        for kb in range(K // 32):
+            for l in (0, 5, 15, 16, 33, 63):
+                r, k0 = rb * 16 + (l & 15), kb * 32 + (l >> 4) * 8
+                assert torch.equal(got[rb, kb, l], wb[r, k0:k0 + 8]), (rb, kb, l)
+    assert lib.car_debug_pack_decode_weight(C.c_void_p(w.data_ptr()), 40, K, C.c_void_p(out.ctypes.data)) != 0   # N % 16 != 0
