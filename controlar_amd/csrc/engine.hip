@@ -1083,8 +1083,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             f.ksq = pick_ks(3 * D, D, bg, f8); f.kso = pick_ks(D, D, bg, f8); f.ks13 = pick_ks(2 * Fh, D, bg, f8); f.ks2 = pick_ks(D, Fh, bg, f8); f.ksl = pick_ks(V, D, bg, f8);
             sizes[gi][0] = (size_t)f.ksq * bg * 3 * D; sizes[gi][1] = (size_t)f.kso * bg * D; sizes[gi][2] = (size_t)f.ks13 * bg * 2 * Fh;
             sizes[gi][3] = (size_t)f.ks2 * bg * D; sizes[gi][4] = (size_t)f.ksl * bg * V;
-            for (int k = 0; k < 5; ++k) tot += sizes[gi][k];
-            tot += (size_t)bg * Hn * gr.nsplit * 66;
+            for (int k = 0; k < 5; ++k) tot += sizes[gi][k];          // each a multiple of 4 floats (N % 4 == 0): 16-byte aligned slices
+            tot += rup((size_t)bg * Hn * gr.nsplit * 66, 4);
         }
         NEED(c, c->dec_parts, tot * 4);
         float* pbase = (float*)c->dec_parts.p;
@@ -1092,7 +1092,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             Grp& gr = grp[gi]; FastBufs& f = gr.fb;
             f.pq = pbase; pbase += sizes[gi][0]; f.po = pbase; pbase += sizes[gi][1]; f.p13 = pbase; pbase += sizes[gi][2];
             f.p2 = pbase; pbase += sizes[gi][3]; f.pl = pbase; pbase += sizes[gi][4];
-            gr.attn_part = pbase; pbase += (size_t)gr.bg * Hn * gr.nsplit * 66;
+            gr.attn_part = pbase; pbase += rup((size_t)gr.bg * Hn * gr.nsplit * 66, 4);
             gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: (pos, step) x 8 chains, then cur_tok
             gr.sp = group_sampler(gi); gr.sp.step_ptr = gr.step;
             gr.sp.logits = nullptr;     // set per launch to the group's logits partials
