@@ -1,0 +1,462 @@
+// decode2.hip — round-2 decode-step kernels (bf16 fast mode): every operand that an MFMA consumes is stored in HBM
+// in the instruction's own fragment order, so a wave moves 1 KiB of contiguous bytes per load instruction straight into
+// the registers the matrix core reads — no LDS staging, no shuffles, no layout fix-ups on the hot path.
+//
+//   dec_gemm   out = epi(X · W^T) for all b sequences of a chain in ONE pass over the weights (reference: the nn.Linear
+//              calls of gpt_t2i.py:264 wqkv, :289 wo, :217 w1/w3/w2, :470 output).  W is the fragment-packed image built at
+//              load time (engine.hip pack_decode_bf16); X is fragment-packed by its producer (rmsnorm / attention /
+//              SwiGLU epilogue).  A workgroup owns an (16·I n) x (16·J m) output tile over the WHOLE K; its waves split K
+//              and fold their accumulators through LDS in a fixed order (deterministic, no fp32 partials in HBM).
+//              Epilogues: QKV (bf16 round, 2-D RoPE, q -> scratch, K/V -> packed cache rows at *pos; gpt_t2i.py:264-277,
+//              :522-532, :227-235), RESID (h = rnd(h + rnd(acc)); gpt_t2i.py:305-306), SWIGLU (rnd(rnd(silu(rnd a)) *
+//              rnd c); gpt_t2i.py:217), LOGITS (bf16 round then widen; gpt_t2i.py:470).
+//   dec_attn2  single-query attention over the valid prefix of the packed KV cache on the matrix cores:
+//              S = K·q (A = K rows in fragment order, B = q broadcast), online softmax on 8 scores per lane,
+//              O += P·V (A = P, B = V in fragment order).  reference: gpt_t2i.py:282-286 + the mask row of
+//              generate.py:184-193; masked slots contribute exactly 0, never-written slots are never touched
+//              (SURVEY.md Appendix E.4).
+//
+// Fragment-packed activation layout ("XP"), X[M][K] bf16:  element (m, k) lives at
+//     (((m/16) * (K/32) + k/32) * 64 + ((k%32)/8) * 16 + m%16) * 8 + k%8
+// i.e. chunk (mb, kb) is the 64-lane x 16-byte operand image of v_mfma_f32_16x16x32_bf16 (lane l: row l&15, k (l>>4)*8..+8).
+// Packed KV cache per (sequence, head) stream of SA = roundup(S_max, 32) positions x 64 dims:
+//     K (p, d): ((p/16)*2 + d/32) * 512 + (((d%32)/8)*16 + p%16) * 8 + d%8           (A operand of S = K·q)
+//     V (p, d): ((p/32)*4 + d/16) * 512 + ((qv*16 + d%16) * 8 + ev),  w = p%32,       (B operand of O = P·V)
+//               (qv, ev) = w < 16 ? (w/4, w%4) : ((w-16)/4, 4 + (w-16)%4)
+// (the V position order inside a 32-block is the order in which the two 16x16 score tiles leave the accumulator, so P
+// needs no cross-lane movement between the two MFMAs).
+#include "car_common.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ inline unsigned pack_bf16x2(float a, float b) {          // v_cvt_pk_bf16_f32 (round-to-nearest-even)
+    const f32x2_t v = {a, b};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return *(const unsigned*)&r;
+}
+
+enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
+
+struct GemmDP {
+    const bf16_t* W;      // packed [N/16][K/32][64][8]
+    const bf16_t* X;      // packed [ceil(M/16)][K/32][64][8]
+    int M, N, K;
+    int w_nt;             // stream W with the non-temporal policy (single M tile: each byte is used once)
+    // EPI_RESID: h[m][n] (row-major, ld = N) updated in place
+    bf16_t* h;
+    // EPI_SWIGLU: packed [ceil(M/16)][(N/2)/32][64][8]
+    bf16_t* outp;
+    // EPI_LOGITS: fp32 [M][N]
+    float* outf;
+    // EPI_QKV
+    bf16_t* qout;         // [M][H][64] rotated q, pre-scaled by head_dim^-0.5
+    bf16_t* kc; bf16_t* vc;   // packed caches of this layer, already offset to the chain's first sequence
+    const float* rope;    // [n_pos][32][2]
+    const int* pos;
+    int H, SA, dim;
+};
+
+template <int I, int J, int WAVES, int EPI>
+__global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];       // [WAVES][I*J][64] f32x4
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nkb = p.K >> 5, Mb = (p.M + 15) >> 4;
+    const int MT = (Mb + J - 1) / J;
+    // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of tiles —
+    // the M tiles that share a weight row-block then hit the same L2
+    int t = blockIdx.x; const int total = gridDim.x;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
+    const int nt = t / MT, mt = t - nt * MT;
+    const int rb0 = nt * I, mb0 = mt * J;
+    const int jn = (Mb - mb0) < J ? (Mb - mb0) : J;                    // m-blocks that exist in this tile (wave-uniform)
+    const int kb_lo = (int)((long)nkb * wave / WAVES), kb_hi = (int)((long)nkb * (wave + 1) / WAVES);
+    const u32x4* wp = (const u32x4*)p.W + (long)rb0 * nkb * 64 + lane;
+    const u32x4* xp = (const u32x4*)p.X + (long)mb0 * nkb * 64 + lane;
+
+    f32x4 acc[I][J];
+#pragma unroll
+    for (int i = 0; i < I; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4 zw = (u32x4){0u, 0u, 0u, 0u};
+    u32x4 wa[I], xa[J], wb[I], xb[J];
+    auto load = [&](u32x4 (&w)[I], u32x4 (&x)[J], int kb) {
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+            const u32x4* a = wp + ((long)i * nkb + kb) * 64;
+            w[i] = p.w_nt ? __builtin_nontemporal_load(a) : *a;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) { x[j] = zw; if (j < jn) x[j] = xp[((long)j * nkb + kb) * 64]; }
+    };
+    auto compute = [&](const u32x4 (&w)[I], const u32x4 (&x)[J]) {
+#pragma unroll
+        for (int i = 0; i < I; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w[i], *(const bf16x8*)&x[j], acc[i][j], 0, 0, 0);
+    };
+    if (kb_lo < kb_hi) load(wa, xa, kb_lo);
+    for (int kb = kb_lo; kb < kb_hi; kb += 2) {
+        if (kb + 1 < kb_hi) load(wb, xb, kb + 1);
+        compute(wa, xa);
+        if (kb + 2 < kb_hi) load(wa, xa, kb + 2);
+        if (kb + 1 < kb_hi) compute(wb, xb);
+    }
+    // ---- fold the WAVES K-slices in fixed order through LDS
+    f32x4* rv = (f32x4*)red;
+#pragma unroll
+    for (int i = 0; i < I; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) rv[((wave * I + i) * J + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+    auto fold = [&](int i, int j) -> f32x4 {
+        f32x4 s = rv[((0 * I + i) * J + j) * 64 + lane];
+        for (int w = 1; w < WAVES; ++w) { const f32x4 v = rv[((w * I + i) * J + j) * 64 + lane]; s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+        return s;
+    };
+    // epilogue units: (pair of adjacent row-blocks, m-block) — the SwiGLU (a, c) pair must meet in one lane
+    constexpr int IP = I >= 2 ? I / 2 : 1, IW = I >= 2 ? 2 : 1;
+    const int q4 = lane >> 4, c16 = lane & 15;
+    for (int u = wave; u < IP * J; u += WAVES) {
+        const int ip = u / J, j = u - ip * J;
+        if (j >= jn) continue;
+        const int m = (mb0 + j) * 16 + c16;
+        f32x4 v[IW];
+#pragma unroll
+        for (int ii = 0; ii < IW; ++ii) v[ii] = fold(ip * IW + ii, j);
+        if (m >= p.M) continue;
+        if (EPI == EPI_SWIGLU) {
+            // row-blocks alternate w1 | w3 (engine.hip car_load_tensor): v[0] = a, v[1] = c for hidden block (rb0/2 + ip)
+            float s[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = bf2f(f2bf(v[0][r])), g = bf2f(f2bf(v[IW - 1][r]));
+                s[r] = bf2f(f2bf(silu_f(a))) * g;
+            }
+            const int hid = ((rb0 >> 1) + ip) * 16 + q4 * 4;            // 4 consecutive hidden units
+            const int nkb2 = p.N >> 6;                                   // (N/2)/32
+            const long off = ((((long)(m >> 4) * nkb2 + (hid >> 5)) * 64 + ((hid & 31) >> 3) * 16 + (m & 15)) << 3) + (hid & 7);
+            uint2 o; o.x = pack_bf16x2(s[0], s[1]); o.y = pack_bf16x2(s[2], s[3]);
+            *(uint2*)(p.outp + off) = o;
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < IW; ++ii) {
+                const int n0 = (rb0 + ip * IW + ii) * 16 + q4 * 4;
+                const f32x4 a = v[ii];
+                if (EPI == EPI_LOGITS) {
+                    float4 o; o.x = bf2f(f2bf(a[0])); o.y = bf2f(f2bf(a[1])); o.z = bf2f(f2bf(a[2])); o.w = bf2f(f2bf(a[3]));
+                    *(float4*)(p.outf + (long)m * p.N + n0) = o;
+                } else if (EPI == EPI_RESID) {
+                    bf16_t* hp = p.h + (long)m * p.N + n0;
+                    const uint2 hv = *(const uint2*)hp;
+                    const float h0 = __uint_as_float(hv.x << 16), h1 = __uint_as_float(hv.x & 0xffff0000u);
+                    const float h2 = __uint_as_float(hv.y << 16), h3 = __uint_as_float(hv.y & 0xffff0000u);
+                    uint2 o;
+                    o.x = pack_bf16x2(h0 + bf2f(f2bf(a[0])), h1 + bf2f(f2bf(a[1])));
+                    o.y = pack_bf16x2(h2 + bf2f(f2bf(a[2])), h3 + bf2f(f2bf(a[3])));
+                    *(uint2*)hp = o;
+                } else {   // EPI_QKV
+                    const int pos = *p.pos;
+                    const int sec = n0 / p.dim, within = n0 - sec * p.dim, hh = within >> 6, d0 = within & 63;
+                    const float x0 = bf2f(f2bf(a[0])), x1 = bf2f(f2bf(a[1])), x2 = bf2f(f2bf(a[2])), x3 = bf2f(f2bf(a[3]));   // Linear output -> bf16
+                    const long sb = ((long)m * p.H + hh) * p.SA * 64;
+                    if (sec == 2) {
+                        const int w = pos & 31, qv = w < 16 ? (w >> 2) : ((w - 16) >> 2), ev = w < 16 ? (w & 3) : (4 + ((w - 16) & 3));
+                        bf16_t* vb = p.vc + sb + ((long)(pos >> 5) * 4 + (d0 >> 4)) * 512 + ((qv * 16 + (d0 & 15)) << 3) + ev;
+                        vb[0] = f2bf(x0); vb[8] = f2bf(x1); vb[16] = f2bf(x2); vb[24] = f2bf(x3);
+                    } else {
+                        const float4 cs = *(const float4*)(p.rope + ((long)pos * 32 + (d0 >> 1)) * 2);   // (cos, sin) of pairs d0/2, d0/2+1
+                        const float r0 = x0 * cs.x - x1 * cs.y, r1 = x1 * cs.x + x0 * cs.y;
+                        const float r2 = x2 * cs.z - x3 * cs.w, r3 = x3 * cs.z + x2 * cs.w;
+                        if (sec == 0) {
+                            // rotated q is rounded to bf16, then scaled by head_dim^-0.5 = 1/8 (exact)
+                            uint2 o;
+                            o.x = pack_bf16x2(bf2f(f2bf(r0)) * 0.125f, bf2f(f2bf(r1)) * 0.125f);
+                            o.y = pack_bf16x2(bf2f(f2bf(r2)) * 0.125f, bf2f(f2bf(r3)) * 0.125f);
+                            *(uint2*)(p.qout + ((long)m * p.H + hh) * 64 + d0) = o;
+                        } else {
+                            uint2 o; o.x = pack_bf16x2(r0, r1); o.y = pack_bf16x2(r2, r3);
+                            bf16_t* kb_ = p.kc + sb + ((long)(pos >> 4) * 2 + (d0 >> 5)) * 512 + ((((d0 & 31) >> 3) * 16 + (pos & 15)) << 3) + (d0 & 7);
+                            *(uint2*)kb_ = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int I, int J, int WAVES>
+static void launch_gemm_ij(const GemmDP& p, int epi, hipStream_t st) {
+    const int Mb = (p.M + 15) / 16, MT = (Mb + J - 1) / J, NT = p.N / (16 * I);
+    const dim3 g(NT * MT), b(WAVES * 64);
+    const size_t sh = (size_t)WAVES * I * J * 64 * 16;
+    static bool attr[4] = {false, false, false, false};
+#define LG(E)                                                                                                                   \
+    do {                                                                                                                        \
+        if (sh > 48 * 1024 && !attr[E]) { (void)hipFuncSetAttribute((const void*)dec_gemm_kernel<I, J, WAVES, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr[E] = true; } \
+        hipLaunchKernelGGL((dec_gemm_kernel<I, J, WAVES, E>), g, b, sh, st, p);                                                  \
+    } while (0)
+    if (epi == EPI_LOGITS) LG(EPI_LOGITS); else if (epi == EPI_RESID) LG(EPI_RESID); else if (epi == EPI_SWIGLU) LG(EPI_SWIGLU); else LG(EPI_QKV);
+#undef LG
+}
+
+// tile shape: I row-blocks x J m-blocks per workgroup, WAVES waves splitting K.  cfg = I*100 + J*10 + (WAVES == 8)
+extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st) {
+    if (epi == EPI_SWIGLU && cfg < 200) return -1;       // the (a, c) pair needs two adjacent row-blocks in one tile
+    if (p->N % (16 * (cfg / 100)) || p->K % 32) return -1;
+    switch (cfg) {
+#define CASE(I, J) case I * 100 + J * 10: launch_gemm_ij<I, J, 4>(*p, epi, st); break; case I * 100 + J * 10 + 1: launch_gemm_ij<I, J, 8>(*p, epi, st); break;
+        CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
+#undef CASE
+        default: return -1;
+    }
+    return 0;
+}
+
+// heuristic tile choice: the widest weight tile that still gives >= ~1 workgroup per CU; 8 waves when K is long
+extern "C" int car_pick_gemm_cfg(int M, int N, int K, int epi) {
+    const int Mb = (M + 15) / 16;
+    const int J = Mb >= 4 ? 4 : (Mb >= 2 ? 2 : 1);
+    const int MT = (Mb + J - 1) / J;
+    const int imin = epi == EPI_SWIGLU ? 2 : 1;
+    int I = 4;
+    while (I > imin && (N % (16 * I) || (N / (16 * I)) * MT < 224)) I >>= 1;
+    return I * 100 + J * 10 + ((K / 32) >= 64 ? 1 : 0);
+}
+
+extern "C" void car_launch_dec_gemm(const GemmDP* p, int epi, hipStream_t st) {
+    (void)car_launch_dec_gemm_cfg(p, epi, car_pick_gemm_cfg(p->M, p->N, p->K, epi), st);
+}
+
+// =============================================================================================== attention
+struct Attn2P {
+    const bf16_t* q;            // [b][H][64] rotated, pre-scaled (EPI_QKV)
+    const bf16_t* kc; const bf16_t* vc;   // packed caches of this layer (chain base)
+    const int* pos;             // device scalar: the new token's position (its K/V row is already in the cache)
+    const unsigned char* mask;  // [b][T] text-pad mask or null
+    bf16_t* out;                // nsplit == 1: attention output, XP-packed [ceil(b/16)][dim/32][64][8] if out_packed else [b][dim]
+    float* part;                // nsplit > 1: [b][H][nsplit][66] (m, l, o[64])
+    int H, SA, T, dim, nsplit, out_packed;
+};
+
+__global__ __launch_bounds__(256) void dec_attn2_kernel(Attn2P p) {
+    __shared__ float red[4][66];
+    const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
+    const int pos = *p.pos;
+    const long sbase = ((long)b * p.H + h) * p.SA * 64;
+    const u32x4* Kp = (const u32x4*)(p.kc + sbase) + lane;
+    const u32x4* Vp = (const u32x4*)(p.vc + sbase) + lane;
+    const bf16_t* qp = p.q + ((long)b * p.H + h) * 64;
+    const bf16x8 qf0 = *(const bf16x8*)(qp + q4 * 8), qf1 = *(const bf16x8*)(qp + 32 + q4 * 8);
+    const unsigned char* mk = p.mask ? p.mask + (long)b * p.T : nullptr;
+    int jmin = 0;
+    if (mk) {       // first attendable text position (left-padded prompts: everything before it is masked)
+        int jm = p.T;
+        for (int j = lane; j < p.T; j += 64) if (mk[j]) { jm = j; break; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) jm = min(jm, __shfl_xor(jm, o, 64));
+        jmin = jm;
+    }
+    const int nblk = (pos >> 5) + 1, NW = p.nsplit * 4;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto load = [&](u32x4 (&kr)[4], u32x4 (&vr)[4], int blk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kr[i] = __builtin_nontemporal_load(Kp + ((long)blk * 4 + i) * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vr[i] = __builtin_nontemporal_load(Vp + ((long)blk * 4 + i) * 64);
+    };
+    auto compute = [&](const u32x4 (&kr)[4], const u32x4 (&vr)[4], int blk) {
+        f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[0], qf0, z4, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[1], qf1, s0, 0, 0, 0);
+        f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[2], qf0, z4, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[3], qf1, s1, 0, 0, 0);
+        float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        const int jb = blk * 32 + q4 * 4;
+        if (blk * 32 + 31 > pos || (mk && blk * 32 < p.T)) {          // wave-uniform: a block that needs per-position masking
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = jb + (e < 4 ? e : 12 + e);
+                const bool ok = j <= pos && !(mk && j < p.T && !mk[j]);
+                if (!ok) sc[e] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx == -INFINITY) return;                                    // wave-uniform: nothing attendable in this block
+        const float mn = fmaxf(m_run, mx), alpha = __expf(m_run - mn);
+        float pe[8], ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pe[e] = __expf(sc[e] - mn); ps += pe[e]; }
+        l_run = l_run * alpha + ps; m_run = mn;
+        u32x4 pu; pu[0] = pack_bf16x2(pe[0], pe[1]); pu[1] = pack_bf16x2(pe[2], pe[3]); pu[2] = pack_bf16x2(pe[4], pe[5]); pu[3] = pack_bf16x2(pe[6], pe[7]);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&pu, *(const bf16x8*)&vr[d], o[d], 0, 0, 0);
+        }
+    };
+    {
+        u32x4 ka[4], va[4], kb2[4], vb2[4];
+        int blk = (jmin >> 5) + split * 4 + wave;
+        if (blk < nblk) load(ka, va, blk);
+        while (blk < nblk) {
+            int nb = blk + NW;
+            if (nb < nblk) load(kb2, vb2, nb);
+            compute(ka, va, blk);
+            blk = nb;
+            if (blk >= nblk) break;
+            nb = blk + NW;
+            if (nb < nblk) load(ka, va, nb);
+            compute(kb2, vb2, blk);
+            blk = nb;
+        }
+    }
+    // ---- merge: every lane of a q-group holds the same l partial; o[d][*] rows are identical (P rows are identical)
+    float lt = l_run + __shfl_xor(l_run, 16, 64); lt += __shfl_xor(lt, 32, 64);
+    if (q4 == 0) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) red[wave][2 + d * 16 + c16] = o[d][0];
+    }
+    if (lane == 0) { red[wave][0] = m_run; red[wave][1] = lt; }
+    __syncthreads();
+    if (tid < 64) {
+        float M = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mm = red[w][0];
+            if (mm > -INFINITY) { const float a = __expf(mm - M); L += red[w][1] * a; O += red[w][2 + tid] * a; }
+        }
+        if (p.nsplit == 1) {
+            const int k = h * 64 + tid;
+            long off;
+            if (p.out_packed) off = ((((long)(b >> 4) * (p.dim >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (b & 15)) << 3) + (k & 7);
+            else off = (long)b * p.dim + k;
+            p.out[off] = f2bf(O / L);
+        } else {
+            float* pt = p.part + (((long)b * p.H + h) * p.nsplit + split) * 66;
+            if (tid == 0) { pt[0] = M; pt[1] = L; }
+            pt[2 + tid] = O;
+        }
+    }
+}
+
+// split-KV combine -> bf16 attention output (XP-packed or row-major)
+__global__ __launch_bounds__(64) void dec_attn2_combine_kernel(const float* part, bf16_t* out, int H, int nsplit, int dim, int out_packed) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const float* pt = part + ((long)b * H + h) * nsplit * 66;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pt[s * 66]);
+    float L = 0.f, O = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float mm = pt[s * 66];
+        if (mm > -INFINITY) { const float a = __expf(mm - M); L += pt[s * 66 + 1] * a; O += pt[s * 66 + 2 + d] * a; }
+    }
+    const int k = h * 64 + d;
+    long off;
+    if (out_packed) off = ((((long)(b >> 4) * (dim >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (b & 15)) << 3) + (k & 7);
+    else off = (long)b * dim + k;
+    out[off] = f2bf(O / L);
+}
+
+extern "C" void car_launch_dec_attn2(const Attn2P* p, int b, hipStream_t st) {
+    hipLaunchKernelGGL(dec_attn2_kernel, dim3(p->H, b, p->nsplit), dim3(256), 0, st, *p);
+    if (p->nsplit > 1 && p->out)
+        hipLaunchKernelGGL(dec_attn2_combine_kernel, dim3(p->H, b), dim3(64), 0, st, p->part, p->out, p->H, p->nsplit, p->dim, p->out_packed);
+}
+
+// =============================================================================================== prefill -> packed cache
+// k/v of the T prefix rows -> packed cache, RoPE on q,k in place (reference: gpt_t2i.py:266-277).  Same arithmetic as
+// decode.hip prefill_rope_kv_kernel; only the cache addressing differs.
+__global__ void prefill_rope_kv2_kernel(bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, const float* rope, int b, int Tn, int H, int dim, int SA) {
+    const long total = (long)b * Tn * H * 32;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int pr = (int)(i % 32); const int h = (int)((i / 32) % H); const int t = (int)((i / (32L * H)) % Tn); const long bb = i / (32L * H * Tn);
+        bf16_t* row = qkv + (bb * Tn + t) * 3 * dim;
+        const float cs = rope[((long)t * 32 + pr) * 2], sn = rope[((long)t * 32 + pr) * 2 + 1];
+        const float q0 = bf2f(row[h * 64 + 2 * pr]), q1 = bf2f(row[h * 64 + 2 * pr + 1]);
+        const float k0 = bf2f(row[dim + h * 64 + 2 * pr]), k1 = bf2f(row[dim + h * 64 + 2 * pr + 1]);
+        row[h * 64 + 2 * pr] = f2bf(q0 * cs - q1 * sn); row[h * 64 + 2 * pr + 1] = f2bf(q1 * cs + q0 * sn);
+        const bf16_t kr0 = f2bf(k0 * cs - k1 * sn), kr1 = f2bf(k1 * cs + k0 * sn);
+        row[dim + h * 64 + 2 * pr] = kr0; row[dim + h * 64 + 2 * pr + 1] = kr1;
+        const long sb = (bb * H + h) * (long)SA * 64;
+        const int d = 2 * pr;
+        bf16_t* kp = kcache + sb + ((long)(t >> 4) * 2 + (d >> 5)) * 512 + ((((d & 31) >> 3) * 16 + (t & 15)) << 3) + (d & 7);
+        kp[0] = kr0; kp[1] = kr1;
+        const int w = t & 31, qv = w < 16 ? (w >> 2) : ((w - 16) >> 2), ev = w < 16 ? (w & 3) : (4 + ((w - 16) & 3));
+        bf16_t* vp = vcache + sb + ((long)(t >> 5) * 4 + (d >> 4)) * 512 + ((qv * 16 + (d & 15)) << 3) + ev;
+        vp[0] = row[2 * dim + h * 64 + d]; vp[8] = row[2 * dim + h * 64 + d + 1];
+    }
+}
+extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, hipStream_t st) {
+    long total = (long)b * Tn * H * 32; int g = (int)((total + 255) / 256); if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(prefill_rope_kv2_kernel, dim3(g), dim3(256), 0, st, (bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, rope, b, Tn, H, dim, SA);
+}
+
+// =============================================================================================== RMSNorm -> packed xn
+// Same arithmetic as ops.hip rmsnorm_kernel<bf16_t> (gpt_t2i.py:193-198, :445, :463/:466) without the split-K residual
+// branch; xn is written in the XP layout that dec_gemm consumes.
+struct Norm2P {
+    const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
+    const bf16_t* ctrl; const int* pos; int add; int T; int n_tok; float cs;
+    int D; float eps;
+};
+__global__ __launch_bounds__(1024) void rmsnorm2_kernel(Norm2P p) {
+    __shared__ float sm[20];
+    const long r = blockIdx.x;
+    const int D = p.D, ng = D >> 2;
+    const bf16_t* src = p.idx ? p.emb + (long)p.idx[r] * D : p.h_in + r * D;
+    const bf16_t* add = p.add ? p.ctrl + (r * p.n_tok + (*p.pos - p.T + 1)) * D : nullptr;
+    float val[4][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int gi = threadIdx.x + q * blockDim.x;
+        if (gi < ng) {
+            const uint2 u = *(const uint2*)(src + gi * 4);
+            float v[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+            if (add) {
+                const uint2 a = *(const uint2*)(add + gi * 4);
+                const float c[4] = {__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e] + bf2f(f2bf(p.cs * c[e]))));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { val[q][e] = v[e]; ss += v[e] * v[e]; }
+        }
+    }
+    const float rstd = rsqrtf(block_sum(ss, sm) / D + p.eps);
+    const int nkb = D >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int gi = threadIdx.x + q * blockDim.x;
+        if (gi < ng) {
+            const int k = gi * 4;
+            if (p.h_out) { uint2 u; u.x = pack_bf16x2(val[q][0], val[q][1]); u.y = pack_bf16x2(val[q][2], val[q][3]); *(uint2*)(p.h_out + r * D + k) = u; }
+            const uint2 wu = *(const uint2*)(p.w + k);
+            const float w[4] = {__uint_as_float(wu.x << 16), __uint_as_float(wu.x & 0xffff0000u), __uint_as_float(wu.y << 16), __uint_as_float(wu.y & 0xffff0000u)};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = bf2f(f2bf(val[q][e] * rstd)) * w[e];
+            uint2 u; u.x = pack_bf16x2(o[0], o[1]); u.y = pack_bf16x2(o[2], o[3]);
+            const long off = ((((r >> 4) * nkb + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (r & 15)) << 3) + (k & 7);
+            *(uint2*)(p.xn + off) = u;
+        }
+    }
+}
+extern "C" void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st) {
+    int ng = p->D / 4, th = ((ng + 63) / 64) * 64; if (th > 1024) th = 1024; if (th < 64) th = 64;
+    hipLaunchKernelGGL(rmsnorm2_kernel, dim3(rows), dim3(th), 0, st, *p);
+}
