@@ -208,236 +208,3 @@ extern "C" void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* 
     else hipLaunchKernelGGL(prefill_rope_kv_kernel<float>, dim3(g), dim3(256), 0, st, qkv, kc, vc, rope, b, Tn, H, dim, S_max);
 }
 
-// =============================================================================================
-// dec_linear (bf16 fast mode): the weight-streaming skinny GEMM of the decode step.
-//   part[ks][m][n] = sum_{k in slice ks} X[m][k] * W[n][k]        m < b <= 16*NB, fp32 partials
-// Weights are pre-packed at load time into MFMA-fragment order: chunk (rb, kb) = the 16x32 tile
-// W[rb*16 .. +16][kb*32 .. +32] stored as 64 lanes x 16 B (lane l: row l&15, k (l>>4)*8 .. +8),
-// chunks ordered [rb][kb]: a wave streaming one row-block over K reads one contiguous run, 1 KiB per
-// global_load_dwordx4 wave-instruction (fully coalesced, non-temporal: each byte is used once per step).
-// v_mfma_f32_16x16x32_bf16 with A = weight chunk, B = X^T fragment from LDS; D[n][m].
-// A workgroup = 4 waves = 4 adjacent row-blocks sharing one LDS copy of the X slice; split-K across
-// workgroups (blockIdx.y); the KS partial slices are summed by the CONSUMER kernel's loads
-// (rmsnorm / dec_attn / next dec_linear / sampler), so no reduction kernel and no atomics:
-// deterministic, fixed summation order.
-struct LinP {
-    const bf16_t* W; const void* X; float* part;
-    int xmode;      // 0: X is bf16 [b][K];  1: X[m][k] = swiglu of fp32 partials [xks][b][2K] in the block-16 interleaved w1|w3 layout;
-                    // 2: X[m][k] = split-KV attention combine of dec_attn partials [b][xh][xks][66] (k = head*64 + d)
-    int xks;
-    int b, N, K, KS;
-    int m0, mrows;  // this launch covers rows [m0, m0+mrows) of the b rows (mrows <= 128); partial/X strides use b
-    int xh;         // xmode 2: number of heads
-};
-
-template <int NB>
-__global__ __launch_bounds__(256) void dec_linear_kernel(LinP p) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t xs[];     // [16*NB][KC + 8]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int KC = p.K / p.KS, nkb = KC / 32, ld = KC + 8;
-    const int ks = blockIdx.y, k0 = ks * KC;
-    const int rb = blockIdx.x * 4 + wave;
-    const bool active = rb * 16 < p.N;
-    const u32x4* wp = (const u32x4*)p.W + ((long)rb * (p.K / 32) + (k0 / 32)) * 64 + lane;
-
-    // first weight batch goes out before X staging so HBM latency overlaps it
-    u32x4 wa[8], wb[8];
-    const u32x4 zw = (u32x4){0u, 0u, 0u, 0u};
-    const uint4 z4 = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { wa[i] = zw; if (active && i < nkb) wa[i] = __builtin_nontemporal_load(wp + (long)i * 64); }
-
-    // ---- stage X[0:16*NB][k0:k0+KC] into LDS (rows >= b are zero)
-    const int rows = 16 * NB, cpr = KC / 8;            // 16-byte chunks per row
-    for (int c = tid; c < rows * cpr; c += 256) {
-        const int m = c / cpr, kc = (c - m * cpr) * 8;
-        uint4 v = z4;
-        if (m < p.mrows) {
-            if (p.xmode == 0) v = *(const uint4*)((const bf16_t*)p.X + (long)(p.m0 + m) * p.K + k0 + kc);
-            else if (p.xmode == 2) {
-                // fold the split-KV combine (dec_attn_combine_kernel) into the staging: fixed split order, same arithmetic
-                const int k = k0 + kc, hh = k >> 6, d0 = k & 63;
-                const float* pt = (const float*)p.X + (((long)(p.m0 + m) * p.xh + hh) * p.xks) * 66;
-                float M = -INFINITY;
-                for (int sidx = 0; sidx < p.xks; ++sidx) M = fmaxf(M, pt[sidx * 66]);
-                float L = 0.f, o8[8];
-#pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8) o8[e8] = 0.f;
-                for (int sidx = 0; sidx < p.xks; ++sidx) {
-                    const float mm = pt[sidx * 66];
-                    if (mm > -INFINITY) {
-                        const float a = expf(mm - M); L += pt[sidx * 66 + 1] * a;
-#pragma unroll
-                        for (int e8 = 0; e8 < 8; ++e8) o8[e8] += pt[sidx * 66 + 2 + d0 + e8] * a;
-                    }
-                }
-                unsigned o[4];
-#pragma unroll
-                for (int e8 = 0; e8 < 8; e8 += 2) o[e8 >> 1] = (unsigned)f2bf(o8[e8] / L) | ((unsigned)f2bf(o8[e8 + 1] / L) << 16);
-                v = make_uint4(o[0], o[1], o[2], o[3]);
-            } else {
-                // hidden index k -> a at column (k/16)*32 + k%16, c at +16 of the interleaved [2K] row; 8 consecutive k stay inside one block of 16
-                const int k = k0 + kc, col = (k >> 4) * 32 + (k & 15);
-                float a[8], g[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { a[e] = 0.f; g[e] = 0.f; }
-                for (int s = 0; s < p.xks; ++s) {
-                    const float* src = (const float*)p.X + ((long)s * p.b + p.m0 + m) * (2L * p.K) + col;
-                    const float4 a0 = *(const float4*)src, a1 = *(const float4*)(src + 4), g0 = *(const float4*)(src + 16), g1 = *(const float4*)(src + 20);
-                    a[0] += a0.x; a[1] += a0.y; a[2] += a0.z; a[3] += a0.w; a[4] += a1.x; a[5] += a1.y; a[6] += a1.z; a[7] += a1.w;
-                    g[0] += g0.x; g[1] += g0.y; g[2] += g0.z; g[3] += g0.w; g[4] += g1.x; g[5] += g1.y; g[6] += g1.z; g[7] += g1.w;
-                }
-                unsigned o[4];
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    // reference rounding points (gpt_t2i.py:217): w1 out ->bf16, silu ->bf16, w3 out ->bf16, product ->bf16
-                    const float s0 = bf2f(f2bf(silu_f(bf2f(f2bf(a[e]))))) * bf2f(f2bf(g[e]));
-                    const float s1 = bf2f(f2bf(silu_f(bf2f(f2bf(a[e + 1]))))) * bf2f(f2bf(g[e + 1]));
-                    o[e >> 1] = (unsigned)f2bf(s0) | ((unsigned)f2bf(s1) << 16);
-                }
-                v = make_uint4(o[0], o[1], o[2], o[3]);
-            }
-        }
-        *(uint4*)(xs + m * ld + kc) = v;
-    }
-    __syncthreads();
-    if (!active) return;
-
-    f32x4 acc[NB];
-#pragma unroll
-    for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bf16_t* xl = xs + (lane & 15) * ld + (lane >> 4) * 8;
-
-    auto compute = [&](const u32x4 (&w)[8], int kb0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (kb0 + i < nkb) {
-                const bf16x8 a = *(const bf16x8*)&w[i];
-#pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    const bf16x8 x = *(const bf16x8*)(xl + n * 16 * ld + (kb0 + i) * 32);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, x, acc[n], 0, 0, 0);
-                }
-            }
-        }
-    };
-    for (int kb0 = 0; kb0 < nkb; kb0 += 16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { wb[i] = zw; if (kb0 + 8 + i < nkb) wb[i] = __builtin_nontemporal_load(wp + (long)(kb0 + 8 + i) * 64); }
-        compute(wa, kb0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { wa[i] = zw; if (kb0 + 16 + i < nkb) wa[i] = __builtin_nontemporal_load(wp + (long)(kb0 + 16 + i) * 64); }
-        compute(wb, kb0 + 8);
-    }
-    // D[row=(lane>>4)*4+r][col=lane&15]: n = rb*16 + (lane>>4)*4 + r, m = nb*16 + (lane&15) -> 16-byte fp32 store per lane
-    const int n0 = rb * 16 + (lane >> 4) * 4;
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-        const int m = n * 16 + (lane & 15);
-        if (m < p.mrows) *(f32x4*)(p.part + ((long)ks * p.b + p.m0 + m) * p.N + n0) = acc[n];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// dec_linear with fp8 (OCP e4m3fn) weights, per-output-row fp32 scales (BASELINE config 5; the reference has no fp8
-// path — SURVEY §8d': a build-side choice, graded by tolerance only).  Weight-only quantisation: each lane's 16-byte
-// load carries its 8-byte fragments of TWO k-blocks; bytes are widened to bf16 in registers (exact: e4m3 is a subset of
-// bf16) and fed to the same v_mfma_f32_16x16x32_bf16; the row scale multiplies the fp32 accumulator in the epilogue.
-// Halves the weight stream (0.75 GB/step for XL).
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ inline bf16x8 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
-    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
-    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
-    u32x4 r;
-    r[0] = (__float_as_uint(a[0]) >> 16) | (__float_as_uint(a[1]) & 0xffff0000u);
-    r[1] = (__float_as_uint(b[0]) >> 16) | (__float_as_uint(b[1]) & 0xffff0000u);
-    r[2] = (__float_as_uint(c[0]) >> 16) | (__float_as_uint(c[1]) & 0xffff0000u);
-    r[3] = (__float_as_uint(d[0]) >> 16) | (__float_as_uint(d[1]) & 0xffff0000u);
-    return *(bf16x8*)&r;
-}
-
-template <int NB>
-__global__ __launch_bounds__(256) void dec_linear_fp8_kernel(LinP p, const float* __restrict__ wscale) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t xs[];     // [16*NB][KC + 8]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int KC = p.K / p.KS, nkp = KC / 64, ld = KC + 8;          // k-block PAIRS per slice
-    const int ks = blockIdx.y, k0 = ks * KC;
-    const int rb = blockIdx.x * 4 + wave;
-    const bool active = rb * 16 < p.N;
-    const u32x4* wp = (const u32x4*)p.W + ((long)rb * (p.K / 64) + (k0 / 64)) * 64 + lane;
-    u32x4 wa[8], wb[8];
-    const u32x4 zw = (u32x4){0u, 0u, 0u, 0u};
-    const uint4 z4 = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { wa[i] = zw; if (active && i < nkp) wa[i] = __builtin_nontemporal_load(wp + (long)i * 64); }
-    const int rows = 16 * NB, cpr = KC / 8;
-    for (int c = tid; c < rows * cpr; c += 256) {
-        const int m = c / cpr, kc = (c - m * cpr) * 8;
-        uint4 v = z4;
-        if (m < p.mrows) v = *(const uint4*)((const bf16_t*)p.X + (long)(p.m0 + m) * p.K + k0 + kc);
-        *(uint4*)(xs + m * ld + kc) = v;
-    }
-    __syncthreads();
-    if (!active) return;
-    f32x4 acc[NB];
-#pragma unroll
-    for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bf16_t* xl = xs + (lane & 15) * ld + (lane >> 4) * 8;
-    auto compute = [&](const u32x4 (&w)[8], int kp0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (kp0 + i < nkp) {
-                const bf16x8 a0 = fp8x8_to_bf16x8(w[i][0], w[i][1]), a1 = fp8x8_to_bf16x8(w[i][2], w[i][3]);
-#pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    const bf16x8 x0 = *(const bf16x8*)(xl + n * 16 * ld + (kp0 + i) * 64);
-                    const bf16x8 x1 = *(const bf16x8*)(xl + n * 16 * ld + (kp0 + i) * 64 + 32);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, x0, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x1, acc[n], 0, 0, 0);
-                }
-            }
-        }
-    };
-    for (int kp0 = 0; kp0 < nkp; kp0 += 16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { wb[i] = zw; if (kp0 + 8 + i < nkp) wb[i] = __builtin_nontemporal_load(wp + (long)(kp0 + 8 + i) * 64); }
-        compute(wa, kp0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { wa[i] = zw; if (kp0 + 16 + i < nkp) wa[i] = __builtin_nontemporal_load(wp + (long)(kp0 + 16 + i) * 64); }
-        compute(wb, kp0 + 8);
-    }
-    const int n0 = rb * 16 + (lane >> 4) * 4;
-    const float4 sc = *(const float4*)(wscale + n0);
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-        const int m = n * 16 + (lane & 15);
-        f32x4 o = acc[n]; o[0] *= sc.x; o[1] *= sc.y; o[2] *= sc.z; o[3] *= sc.w;
-        if (m < p.mrows) *(f32x4*)(p.part + ((long)ks * p.b + p.m0 + m) * p.N + n0) = o;
-    }
-}
-
-extern "C" void car_launch_dec_linear_fp8(const LinP* pp, const float* wscale, hipStream_t st) {
-    const int KC = pp->K / pp->KS;
-    dim3 g((pp->N + 63) / 64, pp->KS);
-    for (int m0 = 0; m0 < pp->b; m0 += 64) {
-        LinP p = *pp; p.m0 = m0; p.mrows = (pp->b - m0) < 64 ? (pp->b - m0) : 64;
-        const int NB = (p.mrows + 15) / 16;
-        if (NB <= 1) hipLaunchKernelGGL(dec_linear_fp8_kernel<1>, g, dim3(256), (size_t)16 * (KC + 8) * 2, st, p, wscale);
-        else if (NB == 2) hipLaunchKernelGGL(dec_linear_fp8_kernel<2>, g, dim3(256), (size_t)32 * (KC + 8) * 2, st, p, wscale);
-        else hipLaunchKernelGGL(dec_linear_fp8_kernel<4>, g, dim3(256), (size_t)64 * (KC + 8) * 2, st, p, wscale);
-    }
-}
-
-// rows are processed in tiles of <= 64 (the dec_linear<4> sweet spot: K-slice of X within 64 KiB of LDS at KC <= 504);
-// a chain with more rows simply issues one launch per tile (weights re-streamed per tile, they sit in the MALL).
-extern "C" void car_launch_dec_linear(const LinP* pp, hipStream_t st) {
-    const int KC = pp->K / pp->KS;
-    dim3 g((pp->N + 63) / 64, pp->KS);
-    for (int m0 = 0; m0 < pp->b; m0 += 64) {
-        LinP p = *pp; p.m0 = m0; p.mrows = (pp->b - m0) < 64 ? (pp->b - m0) : 64;
-        const int NB = (p.mrows + 15) / 16;
-        if (NB <= 1) hipLaunchKernelGGL(dec_linear_kernel<1>, g, dim3(256), (size_t)16 * (KC + 8) * 2, st, p);
-        else if (NB == 2) hipLaunchKernelGGL(dec_linear_kernel<2>, g, dim3(256), (size_t)32 * (KC + 8) * 2, st, p);
-        else hipLaunchKernelGGL(dec_linear_kernel<4>, g, dim3(256), (size_t)64 * (KC + 8) * 2, st, p);
-    }
-}

@@ -44,6 +44,7 @@ struct GemmDP {
     const bf16_t* X;      // packed [ceil(M/16)][K/32][64][8]
     int M, N, K;
     int w_nt;             // stream W with the non-temporal policy (single M tile: each byte is used once)
+    const float* wscale;  // F8 kernels: per-output-row fp32 scale of the e4m3 weight image [N/16][K/64][64][16 B] (engine.hip upload_packed_fp8)
     // EPI_RESID: h[m][n] (row-major, ld = N) updated in place
     bf16_t* h;
     // EPI_SWIGLU: packed [ceil(M/16)][(N/2)/32][64][8]
@@ -58,11 +59,26 @@ struct GemmDP {
     int H, SA, dim;
 };
 
-template <int I, int J, int WAVES, int EPI>
+// OCP e4m3fn bytes -> bf16 (exact: e4m3 is a subset of bf16).  lo/hi: 4 bytes each = 8 consecutive k of one row.
+__device__ inline bf16x8 fp8x8_to_bf16x8_(unsigned lo, unsigned hi) {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    u32x4 r;
+    r[0] = (__float_as_uint(a[0]) >> 16) | (__float_as_uint(a[1]) & 0xffff0000u);
+    r[1] = (__float_as_uint(b[0]) >> 16) | (__float_as_uint(b[1]) & 0xffff0000u);
+    r[2] = (__float_as_uint(c[0]) >> 16) | (__float_as_uint(c[1]) & 0xffff0000u);
+    r[3] = (__float_as_uint(d[0]) >> 16) | (__float_as_uint(d[1]) & 0xffff0000u);
+    return *(bf16x8*)&r;
+}
+
+// F8 = 1: weight-only e4m3 (BASELINE config 5; the reference has no fp8 path): one 16-byte weight load carries the fragments
+// of TWO k-blocks, widened to bf16 in registers; the per-row scale multiplies the folded fp32 sum in the epilogue.
+template <int I, int J, int WAVES, int EPI, int F8>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [WAVES][I*J][64] f32x4
+    constexpr int XPU = F8 ? 2 : 1;                                    // X chunks (k-blocks) per weight load unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nkb = p.K >> 5, Mb = (p.M + 15) >> 4;
+    const int nkb = p.K >> 5, nku = nkb / XPU, Mb = (p.M + 15) >> 4;
     const int MT = (Mb + J - 1) / J;
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of tiles —
     // the M tiles that share a weight row-block then hit the same L2
@@ -71,8 +87,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     const int nt = t / MT, mt = t - nt * MT;
     const int rb0 = nt * I, mb0 = mt * J;
     const int jn = (Mb - mb0) < J ? (Mb - mb0) : J;                    // m-blocks that exist in this tile (wave-uniform)
-    const int kb_lo = (int)((long)nkb * wave / WAVES), kb_hi = (int)((long)nkb * (wave + 1) / WAVES);
-    const u32x4* wp = (const u32x4*)p.W + (long)rb0 * nkb * 64 + lane;
+    const int ku_lo = (int)((long)nku * wave / WAVES), ku_hi = (int)((long)nku * (wave + 1) / WAVES);
+    const u32x4* wp = (const u32x4*)p.W + (long)rb0 * nku * 64 + lane;
     const u32x4* xp = (const u32x4*)p.X + (long)mb0 * nkb * 64 + lane;
 
     f32x4 acc[I][J];
@@ -81,29 +97,41 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 #pragma unroll
         for (int j = 0; j < J; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const u32x4 zw = (u32x4){0u, 0u, 0u, 0u};
-    u32x4 wa[I], xa[J], wb[I], xb[J];
-    auto load = [&](u32x4 (&w)[I], u32x4 (&x)[J], int kb) {
+    u32x4 wa[I], xa[J * XPU], wb[I], xb[J * XPU];
+    auto load = [&](u32x4 (&w)[I], u32x4 (&x)[J * XPU], int ku) {
 #pragma unroll
         for (int i = 0; i < I; ++i) {
-            const u32x4* a = wp + ((long)i * nkb + kb) * 64;
+            const u32x4* a = wp + ((long)i * nku + ku) * 64;
             w[i] = p.w_nt ? __builtin_nontemporal_load(a) : *a;
         }
 #pragma unroll
-        for (int j = 0; j < J; ++j) { x[j] = zw; if (j < jn) x[j] = xp[((long)j * nkb + kb) * 64]; }
-    };
-    auto compute = [&](const u32x4 (&w)[I], const u32x4 (&x)[J]) {
+        for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int i = 0; i < I; ++i)
-#pragma unroll
-            for (int j = 0; j < J; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w[i], *(const bf16x8*)&x[j], acc[i][j], 0, 0, 0);
+            for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (j < jn) x[j * XPU + u] = xp[((long)j * nkb + ku * XPU + u) * 64]; }
     };
-    if (kb_lo < kb_hi) load(wa, xa, kb_lo);
-    for (int kb = kb_lo; kb < kb_hi; kb += 2) {
-        if (kb + 1 < kb_hi) load(wb, xb, kb + 1);
+    auto compute = [&](const u32x4 (&w)[I], const u32x4 (&x)[J * XPU]) {
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+            if (F8) {
+                const bf16x8 a0 = fp8x8_to_bf16x8_(w[i][0], w[i][1]), a1 = fp8x8_to_bf16x8_(w[i][2], w[i][3]);
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, *(const bf16x8*)&x[j * XPU], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, *(const bf16x8*)&x[j * XPU + XPU - 1], acc[i][j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w[i], *(const bf16x8*)&x[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    if (ku_lo < ku_hi) load(wa, xa, ku_lo);
+    for (int ku = ku_lo; ku < ku_hi; ku += 2) {
+        if (ku + 1 < ku_hi) load(wb, xb, ku + 1);
         compute(wa, xa);
-        if (kb + 2 < kb_hi) load(wa, xa, kb + 2);
-        if (kb + 1 < kb_hi) compute(wb, xb);
+        if (ku + 2 < ku_hi) load(wa, xa, ku + 2);
+        if (ku + 1 < ku_hi) compute(wb, xb);
     }
     // ---- fold the WAVES K-slices in fixed order through LDS
     f32x4* rv = (f32x4*)red;
@@ -126,7 +154,13 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
         const int m = (mb0 + j) * 16 + c16;
         f32x4 v[IW];
 #pragma unroll
-        for (int ii = 0; ii < IW; ++ii) v[ii] = fold(ip * IW + ii, j);
+        for (int ii = 0; ii < IW; ++ii) {
+            v[ii] = fold(ip * IW + ii, j);
+            if (F8) {
+                const float4 sc = *(const float4*)(p.wscale + (rb0 + ip * IW + ii) * 16 + q4 * 4);
+                v[ii][0] *= sc.x; v[ii][1] *= sc.y; v[ii][2] *= sc.z; v[ii][3] *= sc.w;
+            }
+        }
         if (m >= p.M) continue;
         if (EPI == EPI_SWIGLU) {
             // row-blocks alternate w1 | w3 (engine.hip car_load_tensor): v[0] = a, v[1] = c for hidden block (rb0/2 + ip)
@@ -189,7 +223,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     }
 }
 
-template <int I, int J, int WAVES>
+template <int I, int J, int WAVES, int F8>
 static void launch_gemm_ij(const GemmDP& p, int epi, hipStream_t st) {
     const int Mb = (p.M + 15) / 16, MT = (Mb + J - 1) / J, NT = p.N / (16 * I);
     const dim3 g(NT * MT), b(WAVES * 64);
@@ -197,8 +231,8 @@ static void launch_gemm_ij(const GemmDP& p, int epi, hipStream_t st) {
     static bool attr[4] = {false, false, false, false};
 #define LG(E)                                                                                                                   \
     do {                                                                                                                        \
-        if (sh > 48 * 1024 && !attr[E]) { (void)hipFuncSetAttribute((const void*)dec_gemm_kernel<I, J, WAVES, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr[E] = true; } \
-        hipLaunchKernelGGL((dec_gemm_kernel<I, J, WAVES, E>), g, b, sh, st, p);                                                  \
+        if (sh > 48 * 1024 && !attr[E]) { (void)hipFuncSetAttribute((const void*)dec_gemm_kernel<I, J, WAVES, E, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr[E] = true; } \
+        hipLaunchKernelGGL((dec_gemm_kernel<I, J, WAVES, E, F8>), g, b, sh, st, p);                                                  \
     } while (0)
     if (epi == EPI_LOGITS) LG(EPI_LOGITS); else if (epi == EPI_RESID) LG(EPI_RESID); else if (epi == EPI_SWIGLU) LG(EPI_SWIGLU); else LG(EPI_QKV);
 #undef LG
@@ -208,8 +242,18 @@ static void launch_gemm_ij(const GemmDP& p, int epi, hipStream_t st) {
 extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st) {
     if (epi == EPI_SWIGLU && cfg < 200) return -1;       // the (a, c) pair needs two adjacent row-blocks in one tile
     if (p->N % (16 * (cfg / 100)) || p->K % 32) return -1;
+    if (p->wscale) {
+        if (p->K % 64) return -1;
+        switch (cfg) {
+#define CASE(I, J) case I * 100 + J * 10: launch_gemm_ij<I, J, 4, 1>(*p, epi, st); break; case I * 100 + J * 10 + 1: launch_gemm_ij<I, J, 8, 1>(*p, epi, st); break;
+            CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
+#undef CASE
+            default: return -1;
+        }
+        return 0;
+    }
     switch (cfg) {
-#define CASE(I, J) case I * 100 + J * 10: launch_gemm_ij<I, J, 4>(*p, epi, st); break; case I * 100 + J * 10 + 1: launch_gemm_ij<I, J, 8>(*p, epi, st); break;
+#define CASE(I, J) case I * 100 + J * 10: launch_gemm_ij<I, J, 4, 0>(*p, epi, st); break; case I * 100 + J * 10 + 1: launch_gemm_ij<I, J, 8, 0>(*p, epi, st); break;
         CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
 #undef CASE
         default: return -1;
@@ -217,15 +261,20 @@ extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStr
     return 0;
 }
 
-// heuristic tile choice: the widest weight tile that still gives >= ~1 workgroup per CU; 8 waves when K is long
+// tile choice from the MI355X sweep of experiments/kbench.hip (profiles/r02_kbench.txt): XL shapes at M = 256/128/64/16/2
 extern "C" int car_pick_gemm_cfg(int M, int N, int K, int epi) {
     const int Mb = (M + 15) / 16;
-    const int J = Mb >= 4 ? 4 : (Mb >= 2 ? 2 : 1);
-    const int MT = (Mb + J - 1) / J;
-    const int imin = epi == EPI_SWIGLU ? 2 : 1;
-    int I = 4;
-    while (I > imin && (N % (16 * I) || (N / (16 * I)) * MT < 224)) I >>= 1;
-    return I * 100 + J * 10 + ((K / 32) >= 64 ? 1 : 0);
+    const bool wideN = N >= 6144, hugeN = N >= 16384, longK = K >= 2048, smallNK = N <= 1536 && K <= 1536;
+    int cfg;
+    if (Mb >= 12) cfg = wideN ? 440 : 241;
+    else if (Mb >= 6) cfg = hugeN ? 440 : (wideN ? 441 : (smallNK ? 110 : 221));
+    else if (Mb >= 3) cfg = hugeN ? 441 : (wideN ? 241 : (longK ? 211 : 110));
+    else if (Mb == 2) cfg = hugeN ? 421 : (wideN ? 221 : (longK ? 121 : 120));
+    else cfg = hugeN ? 411 : (wideN ? 211 : ((longK || smallNK) ? 111 : 110));
+    int I = cfg / 100;
+    if (epi == EPI_SWIGLU && I < 2) I = 2;
+    while (I > 1 && N % (16 * I)) I >>= 1;
+    return I * 100 + cfg % 100;
 }
 
 extern "C" void car_launch_dec_gemm(const GemmDP* p, int epi, hipStream_t st) {
@@ -238,13 +287,17 @@ struct Attn2P {
     const bf16_t* kc; const bf16_t* vc;   // packed caches of this layer (chain base)
     const int* pos;             // device scalar: the new token's position (its K/V row is already in the cache)
     const unsigned char* mask;  // [b][T] text-pad mask or null
+    const int* jmin;            // [b] first attendable text position per sequence (car_launch_mask_first_valid) or null
     bf16_t* out;                // nsplit == 1: attention output, XP-packed [ceil(b/16)][dim/32][64][8] if out_packed else [b][dim]
     float* part;                // nsplit > 1: [b][H][nsplit][66] (m, l, o[64])
     int H, SA, T, dim, nsplit, out_packed;
 };
 
-__global__ __launch_bounds__(256) void dec_attn2_kernel(Attn2P p) {
-    __shared__ float red[4][66];
+// NWAVE waves share one (sequence, head): wave w of split s takes 32-position blocks blk0 + s*NWAVE + w, stride nsplit*NWAVE.
+// PF = 1 keeps the next block's 8 KiB in flight in a second register set while the current one is consumed.
+template <int NWAVE, int PF>
+__global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
+    __shared__ float red[NWAVE][66];
     const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
     const int pos = *p.pos;
@@ -256,13 +309,16 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(Attn2P p) {
     const unsigned char* mk = p.mask ? p.mask + (long)b * p.T : nullptr;
     int jmin = 0;
     if (mk) {       // first attendable text position (left-padded prompts: everything before it is masked)
-        int jm = p.T;
-        for (int j = lane; j < p.T; j += 64) if (mk[j]) { jm = j; break; }
+        if (p.jmin) jmin = p.jmin[b];
+        else {
+            int jm = p.T;
+            for (int j = lane; j < p.T; j += 64) { const int v = mk[j]; if (v != 0 && j < jm) jm = j; }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) jm = min(jm, __shfl_xor(jm, o, 64));
-        jmin = jm;
+            for (int o = 32; o > 0; o >>= 1) jm = min(jm, __shfl_xor(jm, o, 64));
+            jmin = jm;
+        }
     }
-    const int nblk = (pos >> 5) + 1, NW = p.nsplit * 4;
+    const int nblk = (pos >> 5) + 1, NW = p.nsplit * NWAVE;
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 o[4];
 #pragma unroll
@@ -282,32 +338,37 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(Attn2P p) {
         s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[3], qf1, s1, 0, 0, 0);
         float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
         const int jb = blk * 32 + q4 * 4;
-        if (blk * 32 + 31 > pos || (mk && blk * 32 < p.T)) {          // wave-uniform: a block that needs per-position masking
+        const bool use_mk = mk != nullptr && blk * 32 < p.T;           // wave-uniform
+        if (use_mk || blk * 32 + 31 > pos) {                           // wave-uniform: a block that needs per-position masking
+            // branch-free selects (a short-circuit form of this test was mis-compiled by hipcc 7.2: the mask byte was loaded and dropped)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int j = jb + (e < 4 ? e : 12 + e);
-                const bool ok = j <= pos && !(mk && j < p.T && !mk[j]);
-                if (!ok) sc[e] = -INFINITY;
+                unsigned mv = 1u;
+                if (use_mk) mv = mk[min(j, p.T - 1)];
+                const bool ok = (j <= pos) & ((j >= p.T) | (mv != 0u));
+                sc[e] = ok ? sc[e] : -INFINITY;
             }
         }
         float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (mx == -INFINITY) return;                                    // wave-uniform: nothing attendable in this block
-        const float mn = fmaxf(m_run, mx), alpha = __expf(m_run - mn);
-        float pe[8], ps = 0.f;
+        if (mx > -INFINITY) {                                           // wave-uniform: something attendable in this block
+            const float mn = fmaxf(m_run, mx), alpha = __expf(m_run - mn);
+            float pe[8], ps = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { pe[e] = __expf(sc[e] - mn); ps += pe[e]; }
-        l_run = l_run * alpha + ps; m_run = mn;
-        u32x4 pu; pu[0] = pack_bf16x2(pe[0], pe[1]); pu[1] = pack_bf16x2(pe[2], pe[3]); pu[2] = pack_bf16x2(pe[4], pe[5]); pu[3] = pack_bf16x2(pe[6], pe[7]);
+            for (int e = 0; e < 8; ++e) { pe[e] = __expf(sc[e] - mn); ps += pe[e]; }
+            l_run = l_run * alpha + ps; m_run = mn;
+            u32x4 pu; pu[0] = pack_bf16x2(pe[0], pe[1]); pu[1] = pack_bf16x2(pe[2], pe[3]); pu[2] = pack_bf16x2(pe[4], pe[5]); pu[3] = pack_bf16x2(pe[6], pe[7]);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
-            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&pu, *(const bf16x8*)&vr[d], o[d], 0, 0, 0);
+            for (int d = 0; d < 4; ++d) {
+                o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&pu, *(const bf16x8*)&vr[d], o[d], 0, 0, 0);
+            }
         }
     };
-    {
+    if (PF) {
         u32x4 ka[4], va[4], kb2[4], vb2[4];
-        int blk = (jmin >> 5) + split * 4 + wave;
+        int blk = (jmin >> 5) + split * NWAVE + wave;
         if (blk < nblk) load(ka, va, blk);
         while (blk < nblk) {
             int nb = blk + NW;
@@ -320,6 +381,9 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(Attn2P p) {
             compute(kb2, vb2, blk);
             blk = nb;
         }
+    } else {
+        u32x4 ka[4], va[4];
+        for (int blk = (jmin >> 5) + split * NWAVE + wave; blk < nblk; blk += NW) { load(ka, va, blk); compute(ka, va, blk); }
     }
     // ---- merge: every lane of a q-group holds the same l partial; o[d][*] rows are identical (P rows are identical)
     float lt = l_run + __shfl_xor(l_run, 16, 64); lt += __shfl_xor(lt, 32, 64);
@@ -330,12 +394,15 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(Attn2P p) {
     if (lane == 0) { red[wave][0] = m_run; red[wave][1] = lt; }
     __syncthreads();
     if (tid < 64) {
-        float M = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+        float M = red[0][0];
+#pragma unroll
+        for (int w = 1; w < NWAVE; ++w) M = fmaxf(M, red[w][0]);
         float L = 0.f, O = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NWAVE; ++w) {
             const float mm = red[w][0];
-            if (mm > -INFINITY) { const float a = __expf(mm - M); L += red[w][1] * a; O += red[w][2 + tid] * a; }
+            const float a = mm > -INFINITY ? __expf(mm - M) : 0.f;
+            L += red[w][1] * a; O += red[w][2 + tid] * a;
         }
         if (p.nsplit == 1) {
             const int k = h * 64 + tid;
@@ -349,6 +416,31 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(Attn2P p) {
             pt[2 + tid] = O;
         }
     }
+}
+
+// text-pad mask rows for the decode batch: out[r][t] = emb_mask[row_img[r]][t] != 0 (all ones without a mask); generate.py:184-193
+__global__ void build_mask_kernel(const int64_t* emb_mask, const int* row_img, unsigned char* out, int b, int T) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)b * T) return;
+    const int r = (int)(i / T), t = (int)(i - (long)r * T);
+    out[i] = emb_mask ? (unsigned char)(emb_mask[(long)row_img[r] * T + t] != 0) : (unsigned char)1;
+}
+extern "C" void car_launch_build_mask(const int64_t* emb_mask, const int* row_img, unsigned char* out, int b, int T, hipStream_t st) {
+    const long n = (long)b * T;
+    hipLaunchKernelGGL(build_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, emb_mask, row_img, out, b, T);
+}
+
+// jmin[b] = first position of the text prefix that may be attended (T if none); once per generate call
+__global__ void mask_first_valid_kernel(const unsigned char* mask, int* jmin, int T) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int jm = T;
+    for (int j = lane; j < T; j += 64) { const int v = mask[(long)b * T + j]; if (v != 0 && j < jm) jm = j; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) jm = min(jm, __shfl_xor(jm, o, 64));
+    if (lane == 0) jmin[b] = jm;
+}
+extern "C" void car_launch_mask_first_valid(const unsigned char* mask, int* jmin, int b, int T, hipStream_t st) {
+    hipLaunchKernelGGL(mask_first_valid_kernel, dim3(b), dim3(64), 0, st, mask, jmin, T);
 }
 
 // split-KV combine -> bf16 attention output (XP-packed or row-major)
@@ -369,12 +461,19 @@ __global__ __launch_bounds__(64) void dec_attn2_combine_kernel(const float* part
     out[off] = f2bf(O / L);
 }
 
-extern "C" void car_launch_dec_attn2(const Attn2P* p, int b, hipStream_t st) {
-    hipLaunchKernelGGL(dec_attn2_kernel, dim3(p->H, b, p->nsplit), dim3(256), 0, st, *p);
+// variant = NWAVE*10 + PF  (42 = default: 4 waves, prefetch... see DESIGN.md for the measured choice)
+extern "C" void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, hipStream_t st) {
+    const dim3 g(p->H, b, p->nsplit);
+    switch (variant) {
+        case 20: hipLaunchKernelGGL((dec_attn2_kernel<2, 0>), g, dim3(128), 0, st, *p); break;
+        case 21: hipLaunchKernelGGL((dec_attn2_kernel<2, 1>), g, dim3(128), 0, st, *p); break;
+        case 40: hipLaunchKernelGGL((dec_attn2_kernel<4, 0>), g, dim3(256), 0, st, *p); break;
+        default: hipLaunchKernelGGL((dec_attn2_kernel<4, 1>), g, dim3(256), 0, st, *p); break;
+    }
     if (p->nsplit > 1 && p->out)
         hipLaunchKernelGGL(dec_attn2_combine_kernel, dim3(p->H, b), dim3(64), 0, st, p->part, p->out, p->H, p->nsplit, p->dim, p->out_packed);
 }
-
+extern "C" void car_launch_dec_attn2(const Attn2P* p, int b, hipStream_t st) { car_launch_dec_attn2_var(p, b, 41, st); }
 // =============================================================================================== prefill -> packed cache
 // k/v of the T prefix rows -> packed cache, RoPE on q,k in place (reference: gpt_t2i.py:266-277).  Same arithmetic as
 // decode.hip prefill_rope_kv_kernel; only the cache addressing differs.

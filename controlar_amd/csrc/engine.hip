@@ -35,14 +35,30 @@ struct AttnP {
     void* out; float* part; int H, S_max, T, dim, nsplit;
     const float* qkv_parts; int qkv_ks; long qkv_stride;
 };
-struct LinP {
-    const bf16_t* W; const void* X; float* part;
-    int xmode; int xks;
-    int b, N, K, KS;
-    int m0, mrows;
-    int xh;
+// decode2.hip
+enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
+struct GemmDP {
+    const bf16_t* W; const bf16_t* X; int M, N, K; int w_nt; const float* wscale;
+    bf16_t* h; bf16_t* outp; float* outf;
+    bf16_t* qout; bf16_t* kc; bf16_t* vc; const float* rope; const int* pos; int H, SA, dim;
+};
+struct Attn2P {
+    const bf16_t* q; const bf16_t* kc; const bf16_t* vc; const int* pos; const unsigned char* mask; const int* jmin;
+    bf16_t* out; float* part; int H, SA, T, dim, nsplit, out_packed;
+};
+struct Norm2P {
+    const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
+    const bf16_t* ctrl; const int* pos; int add; int T; int n_tok; float cs;
+    int D; float eps;
 };
 extern "C" {
+int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st);
+int car_pick_gemm_cfg(int M, int N, int K, int epi);
+void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, hipStream_t st);
+void car_launch_mask_first_valid(const unsigned char* mask, int* jmin, int b, int T, hipStream_t st);
+void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, hipStream_t st);
+void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st);
+void car_launch_build_mask(const int64_t* emb_mask, const int* row_img, unsigned char* out, int b, int T, hipStream_t st);
 void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
 void car_launch_convert(int mode, const void* src, int src_dtype, void* dst, long n, hipStream_t st);
 void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg, hipStream_t st);
@@ -64,10 +80,7 @@ void car_launch_sample_greedy(const SampleP* p, hipStream_t st);
 void car_launch_advance(int* pos, int* step, hipStream_t st);
 void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st);
 void car_launch_dec_attn(int mode, const AttnP* p, int b, hipStream_t st);
-void car_launch_dec_linear(const LinP* p, hipStream_t st);
-void car_launch_dec_linear_fp8(const LinP* p, const float* wscale, hipStream_t st);
 void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st);
-void car_launch_swiglu_parts(const float* parts, int ks, long stride, void* out, int rows, int hidden, hipStream_t st);
 void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, hipStream_t st);
 }
 
@@ -113,6 +126,10 @@ struct car_ctx {
     DevBuf scal;         // device ints: pos, step, cur_tok[b]
     DevBuf tok_out;      // [B, n_new] int32
     DevBuf maskb;        // [b, T] uint8
+    std::vector<int> h_rowimg;          // host staging that must outlive the async copies of a generate call
+    int h_init[16] = {};
+    DevBuf rowimg;       // [b] int: image index of each row
+    int st_b = 0, st_T = 0, st_nsteps = 0, st_has_mask = 0; double st_wbytes = 0; const int* st_jmin = nullptr;   // inputs of the lazy decode_algo_bytes
     // decode graph
     hipGraphExec_t gexec = nullptr; std::string gkey;
     car_stats stats;
@@ -199,7 +216,7 @@ extern "C" void car_destroy(car_ctx* c) {
     for (auto& kv : c->resize_cache) { (void)hipFree(kv.second.iy); (void)hipFree(kv.second.ix); if (kv.second.wy) (void)hipFree(kv.second.wy); if (kv.second.wx) (void)hipFree(kv.second.wx); }
     if (c->rope) (void)hipFree(c->rope);
     c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
-    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release();
+    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
     (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 7; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); }
@@ -718,96 +735,73 @@ extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype
 // ------------------------------------------------------------------------------------- decode step (one token for all b sequences)
 struct StepBufs { void *h, *xn, *qkv, *att, *mid, *mid2; float* part; float* logits; int *pos, *step, *cur; };
 
-// split-K factor of a decode linear: enough workgroups to cover the chip, X slice within 64 KiB of LDS
-static int pick_ks(int N, int K, int b, bool pairs = false) {
-    const int rg = (N + 63) / 64, nkb = K / 32, NB = b <= 16 ? 1 : (b <= 32 ? 2 : 4);     // rows are tiled by 64 per launch
-    const int kc_max = 65536 / (32 * NB) - 8;
-    int best = -1;
-    for (int d = 1; d <= nkb; ++d) {
-        if (nkb % d) continue;
-        const int KC = K / d;
-        if (pairs && KC % 64) continue;
-        if (KC > kc_max) continue;
-        if (best < 0) best = d;
-        if (KC < 128) break;
-        best = d;
-        if (rg * d >= 200) break;
-    }
-    return best < 0 ? nkb : best;
-}
+// A chain = a contiguous slice [b0, b0+bg) of the sequences decoded as its own dependency chain.  With several chains the
+// captured step has parallel branches: one chain's HBM-bound attention overlaps the other chains' latency-bound GEMMs
+// (each chain re-streams the weights; a layer's 40 MB sits in the 256 MiB MALL between chains).
+struct FastBufs { bf16_t *xn, *att, *mid, *q; float* logits; float* attn_part; };     // per-chain scratch (XP-packed activations)
+struct Grp { int b0, bg, nsplit; int *pos, *step; FastBufs fb; SampleP sp; };
 
-struct FastBufs { float *pq, *po, *p13, *p2, *pl; int ksq, kso, ks13, ks2, ksl; };
-
-// A group = a contiguous slice [b0, b0+bg) of the sequences decoded as its own dependency chain.  With two
-// groups the captured step has two parallel branches: one chain's bandwidth-bound attention overlaps the
-// other chain's latency-bound small kernels (each chain re-reads the weights; they mostly hit the 256 MiB MALL).
-struct Grp { int b0, bg, nsplit; int *pos, *step; FastBufs fb; SampleP sp; float* attn_part; };
-
-// bf16 fast path: 8 kernels per layer, every linear is a dec_linear whose split-K partials are summed by its consumer
-static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& gr, int b_total, int S_max, int n_tok, bool use_ctrl,
-                                    float cs, hipStream_t st) {
-    const car_config& g = c->cfg; const size_t e = c->esz;
-    const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, li = g.n_layer / 3, V = g.vocab_size;
+// bf16 fast path (decode2.hip): 7 kernels per layer — norm -> wqkv(+RoPE, KV write) -> attention -> wo(+residual) ->
+// norm -> w1|w3(+SwiGLU) -> w2(+residual); every linear streams the weights once for all rows of the chain.
+static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& gr, int b_total, int SA, int n_tok, bool use_ctrl,
+                                    float cs, const unsigned char* maskb, const int* jmin, hipStream_t st) {
+    const car_config& g = c->cfg;
+    const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, li = g.n_layer / 3, V = g.vocab_size, T = g.cls_token_num;
     const int b = gr.bg, b0 = gr.b0, nsplit = gr.nsplit;
     const FastBufs& fb = gr.fb;
-    const size_t kv_layer = (size_t)b_total * Hn * S_max * 64, kv_off = (size_t)b0 * Hn * S_max * 64;
-    void* h = off(sb.h, (size_t)b0 * D, e); void* xn = off(sb.xn, (size_t)b0 * D, e); void* att = off(sb.att, (size_t)b0 * D, e);
-    void* mid = off(sb.mid, (size_t)b0 * Fh, e);
-    const unsigned char* mask = (const unsigned char*)c->maskb.p + (size_t)b0 * g.cls_token_num;
+    const size_t kv_layer = (size_t)b_total * Hn * SA * 64, kv_off = (size_t)b0 * Hn * SA * 64;
+    bf16_t* h = (bf16_t*)sb.h + (size_t)b0 * D;
+    const bool f8 = g.decode_weight_fp8 != 0;
     int nk = 0;
-    // small chains (<= 16 rows): the split-KV combine and the SwiGLU are folded into the X staging of the next linear
-    // (2 fewer dependent kernels per layer; the redundant per-workgroup recomputation is negligible at this size)
-    const bool fuse_small = b <= 16 && !g.decode_weight_fp8 && !getenv("CAR_NO_SMALL_FUSE");
-    auto lin = [&](const std::string& wname, const void* X, float* part, int N, int K, int KS, int xmode = 0, int xks = 0) {
-        const bool f8 = g.decode_weight_fp8 != 0;
-        LinP lp; lp.W = (const bf16_t*)Wp(c, wname + (f8 ? "#pk8" : "#pk")); lp.X = X; lp.part = part; lp.xmode = xmode; lp.xks = xks; lp.xh = Hn; lp.b = b; lp.N = N; lp.K = K; lp.KS = KS; lp.m0 = 0; lp.mrows = b;
-        if (f8) car_launch_dec_linear_fp8(&lp, (const float*)Wp(c, wname + "#sc"), st); else car_launch_dec_linear(&lp, st);
-        nk += (b + 63) / 64;
+    auto gemm = [&](const std::string& wname, const bf16_t* X, int N, int K, int epi, GemmDP gp_) {
+        GemmDP p = gp_;
+        p.W = (const bf16_t*)Wp(c, wname + (f8 ? "#pk8" : "#pk")); p.X = X; p.M = b; p.N = N; p.K = K;
+        p.wscale = f8 ? (const float*)Wp(c, wname + "#sc") : nullptr;
+        const int cfg = car_pick_gemm_cfg(b, N, K, epi);
+        const int J = (cfg / 10) % 10, Mb = (b + 15) / 16;
+        p.w_nt = (Mb + J - 1) / J == 1;
+        car_launch_dec_gemm_cfg(&p, epi, cfg, st); ++nk;
     };
+    GemmDP z; memset(&z, 0, sizeof(z));
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
-        {   // [token gather | + previous layer's FFN output] (+ control add) -> h ; attention_norm -> xn
-            NormP np; memset(&np, 0, sizeof(np));
-            np.h_in = h; np.h_out = h; np.xn = xn; np.w = Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
-            if (l == 0) { np.emb = Wp(c, "tok_embeddings.weight"); np.idx = sb.cur + b0; }
-            else { np.parts = fb.p2; np.parts_ks = fb.ks2; np.parts_stride = (long)b * D; }
-            if (use_ctrl && l % li == 0 && l / li < 3) { np.add_mode = 1; np.ctrl = off(c->ctrl[l / li].p, (size_t)b0 * n_tok * D, e); np.pos = gr.pos; np.T = g.cls_token_num; np.n_tok = n_tok; np.cs = cs; }
-            car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
+        {   // [token gather at layer 0] (+ control add at layers 0, n/3, 2n/3) -> h ; attention_norm -> xn (packed)
+            Norm2P np; memset(&np, 0, sizeof(np));
+            np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            if (l == 0) { np.emb = (const bf16_t*)Wp(c, "tok_embeddings.weight"); np.idx = sb.cur + b0; np.h_out = h; }
+            if (use_ctrl && l % li == 0 && l / li < 3) {
+                np.add = 1; np.ctrl = (const bf16_t*)c->ctrl[l / li].p + (size_t)b0 * n_tok * D; np.pos = gr.pos; np.T = T; np.n_tok = n_tok; np.cs = cs; np.h_out = h;
+            }
+            car_launch_rmsnorm2(&np, b, st); ++nk;
         }
-        lin(L + "attention.wqkv.weight", xn, fb.pq, 3 * D, D, fb.ksq);
+        bf16_t* kc = (bf16_t*)c->kv.p + (size_t)(2 * l) * kv_layer + kv_off; bf16_t* vc = (bf16_t*)c->kv.p + (size_t)(2 * l + 1) * kv_layer + kv_off;
         {
-            AttnP ap; memset(&ap, 0, sizeof(ap));
-            ap.kcache = off(c->kv.p, (size_t)(2 * l) * kv_layer + kv_off, e); ap.vcache = off(c->kv.p, (size_t)(2 * l + 1) * kv_layer + kv_off, e);
-            const bool fold = fuse_small && nsplit > 1;
-            ap.rope = c->rope; ap.pos = gr.pos; ap.emb_mask = mask; ap.out = fold ? nullptr : att; ap.part = gr.attn_part;
-            ap.H = Hn; ap.S_max = S_max; ap.T = g.cls_token_num; ap.dim = D; ap.nsplit = nsplit;
-            ap.qkv_parts = fb.pq; ap.qkv_ks = fb.ksq; ap.qkv_stride = (long)b * 3 * D;
-            car_launch_dec_attn(CAR_BF16, &ap, b, st); nk += (nsplit > 1 && !fold) ? 2 : 1;
-            if (fold) lin(L + "attention.wo.weight", gr.attn_part, fb.po, D, D, fb.kso, 2, nsplit);
-            else lin(L + "attention.wo.weight", att, fb.po, D, D, fb.kso);
+            GemmDP q = z; q.qout = fb.q; q.kc = kc; q.vc = vc; q.rope = c->rope; q.pos = gr.pos; q.H = Hn; q.SA = SA; q.dim = D;
+            gemm(L + "attention.wqkv.weight", fb.xn, 3 * D, D, EPI_QKV, q);
         }
-        {   // h += attention output ; ffn_norm -> xn
-            NormP np; memset(&np, 0, sizeof(np));
-            np.h_in = h; np.h_out = h; np.xn = xn; np.w = Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps;
-            np.parts = fb.po; np.parts_ks = fb.kso; np.parts_stride = (long)b * D;
-            car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
+        {
+            Attn2P ap; memset(&ap, 0, sizeof(ap));
+            ap.q = fb.q; ap.kc = kc; ap.vc = vc; ap.pos = gr.pos; ap.mask = maskb ? maskb + (size_t)b0 * T : nullptr; ap.jmin = jmin ? jmin + b0 : nullptr;
+            ap.out = fb.att; ap.part = fb.attn_part; ap.H = Hn; ap.SA = SA; ap.T = T; ap.dim = D; ap.nsplit = nsplit; ap.out_packed = 1;
+            car_launch_dec_attn2_var(&ap, b, (nsplit == 1 && b < 128) ? 20 : 40, st); nk += nsplit > 1 ? 2 : 1;
         }
-        lin(L + "feed_forward.w13.weight", xn, fb.p13, 2 * Fh, D, fb.ks13);
-        if (fuse_small) lin(L + "feed_forward.w2.weight", fb.p13, fb.p2, D, Fh, fb.ks2, 1, fb.ks13);
-        else {
-            car_launch_swiglu_parts(fb.p13, fb.ks13, (long)b * 2 * Fh, mid, b, Fh, st); ++nk;
-            lin(L + "feed_forward.w2.weight", mid, fb.p2, D, Fh, fb.ks2);
+        { GemmDP q = z; q.h = h; gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
+        {
+            Norm2P np; memset(&np, 0, sizeof(np));
+            np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            car_launch_rmsnorm2(&np, b, st); ++nk;
         }
+        { GemmDP q = z; q.outp = fb.mid; gemm(L + "feed_forward.w13.weight", fb.xn, 2 * Fh, D, EPI_SWIGLU, q); }
+        { GemmDP q = z; q.h = h; gemm(L + "feed_forward.w2.weight", fb.mid, D, Fh, EPI_RESID, q); }
     }
-    {   // h += last FFN output ; final norm
-        NormP np; memset(&np, 0, sizeof(np));
-        np.h_in = h; np.h_out = h; np.xn = xn; np.w = Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps;
-        np.parts = fb.p2; np.parts_ks = fb.ks2; np.parts_stride = (long)b * D;
-        car_launch_rmsnorm(CAR_BF16, &np, b, st); ++nk;
+    {
+        Norm2P np; memset(&np, 0, sizeof(np));
+        np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps;
+        car_launch_rmsnorm2(&np, b, st); ++nk;
     }
-    lin("output.weight", xn, fb.pl, V, D, fb.ksl);
+    { GemmDP q = z; q.outf = fb.logits; gemm("output.weight", fb.xn, V, D, EPI_LOGITS, q); }
     car_launch_advance(gr.pos, gr.step, st); ++nk;
-    SampleP sp = gr.sp; sp.logits = fb.pl; sp.logits_ks = fb.ksl; sp.logits_stride = (long)b * V; sp.round_bf16 = 1;
+    SampleP sp = gr.sp; sp.logits = fb.logits; sp.logits_ks = 0; sp.round_bf16 = 0;
     car_launch_sample_greedy(&sp, st); ++nk;
     c->n_dec_kernels = nk;
     return 0;
@@ -898,6 +892,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     const int b = use_cfg ? 2 * B : B;
     const float cs = (use_cfg && !c2i) ? sp->control_strength : 1.0f;   // generate.py:87-92: strength ignored when cfg <= 1; absent in gpt.py
     const int S_max = (int)rup(T + n_new, 8);                       // gpt_t2i.py:395
+    const int SA = c->mode == CAR_BF16 ? (int)rup(S_max, 32) : S_max;   // fast mode: packed KV streams hold whole 32-position blocks (decode2.hip)
     const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, V = g.vocab_size, n_tok = c->ctrl_ntok, li = g.n_layer / 3;
     const int mode = c->mode; const size_t e = c->esz;
     hipStream_t caller = (hipStream_t)stream_, st = c->stream;
@@ -908,10 +903,9 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     // reference layout [cond 0..B-1 | uncond 0..B-1] (generate.py:158-163).
     const bool fast = mode == CAR_BF16;
     const int mult = use_cfg ? 2 : 1;
-    // chains of <= 64 rows (the dec_linear<4> sweet spot); measured on MI355X (XL, tools/decode_probe.py): one chain wins up to
-    // b = 32 (2.55 vs 2.67 ms/step), break-even at 48, two chains win from 64 (3.09 vs 3.14) and clearly at 96 (3.79 vs 4.32)
-    int NG = (fast && b >= 48) ? (b <= 64 ? 2 : (b + 63) / 64) : 1;
-    if (NG > 8) NG = 8;
+    // two chains from 192 sequences up: each chain's GEMMs stream the weights once for <= 128+ rows, and one chain's HBM-bound
+    // attention runs beside the other's latency-bound GEMMs (profiles/r02_decode_chain_sweep.txt)
+    int NG = (fast && b >= 192) ? 2 : 1;
     if (fast) { const char* ev = getenv("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 8 && B / v >= 2) NG = v; } }
     if (getenv("CAR_SINGLE_CHAIN") || NG > B) NG = 1;
     int img0[9];
@@ -924,8 +918,10 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     }
 
     // ---- buffers
-    const size_t kv_layer = (size_t)b * Hn * S_max * 64;
+    const size_t kv_layer = (size_t)b * Hn * SA * 64;
+    const void* kv_before = c->kv.p;
     NEED(c, c->kv, (size_t)g.n_layer * 2 * kv_layer * e);
+    const bool kv_fresh = c->kv.p != kv_before;
     const long rowsP = (long)b * T;
     NEED(c, c->ws[0], (size_t)b * T * g.caption_dim * e);                     // text input (cond | uncond)
     NEED(c, c->ws[1], (size_t)rowsP * D * e);                                 // h (prefill)
@@ -941,7 +937,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     { const int wg = b * Hn; while (wg * nsplit < 1024 && nsplit < 16) nsplit *= 2; }
     NEED(c, c->ws[10], (size_t)b * Hn * nsplit * 66 * 4);                     // split-KV partials
     NEED(c, c->ws[11], (size_t)B * (use_control ? n_tok : 1) * D * e);        // condition_mlp output / mlp mid
-    NEED(c, c->scal, (size_t)(16 + b) * 4);
+    NEED(c, c->scal, (size_t)(16 + 2 * b) * 4);
+    NEED(c, c->rowimg, (size_t)b * 4);
     NEED(c, c->tok_out, (size_t)B * n_new * 4);
     NEED(c, c->maskb, (size_t)b * T);
     for (int k = 0; k < 3; ++k) if (use_control) NEED(c, c->ctrl[k], (size_t)b * n_tok * D * e);
@@ -949,25 +946,19 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     fence_in(c, caller);
     HIPCHK(c, hipEventRecord(c->ev_t0, st));
     // The reference zero-fills fresh KVCache buffers every call (gpt_t2i.py:223-225, :391-405); slots that
-    // were never written are always masked there and never read here (dec_attn walks only valid rows), so
-    // no memset is needed.
-    // text-pad mask -> uint8 [b, T] (both CFG halves share it, generate.py:188)
+    // were never written are always masked there and never read here (the attention kernels walk only valid rows), so
+    // no per-call memset is needed.  A FRESH allocation is cleared once: the packed V stream is
+    // consumed in 32-position blocks whose tail rows meet a zero probability — they must be finite, not uninitialised bits.
+    if (kv_fresh) HIPCHK(c, hipMemsetAsync(c->kv.p, 0, c->kv.cap, st));
+    // text-pad mask -> uint8 [b, T] (both CFG halves share it, generate.py:188), built on the device: no host round trip
+    c->h_rowimg.assign(row_img.begin(), row_img.end());
+    HIPCHK(c, hipMemcpyAsync(c->rowimg.p, c->h_rowimg.data(), (size_t)b * 4, hipMemcpyHostToDevice, st));
+    car_launch_build_mask(emb_mask, (const int*)c->rowimg.p, (unsigned char*)c->maskb.p, b, T, st);
+    int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 16; int* jmin = cur + b;
+    if (emb_mask) car_launch_mask_first_valid((const unsigned char*)c->maskb.p, jmin, b, T, st);
     {
-        std::vector<unsigned char> mk((size_t)b * T, 1);
-        if (emb_mask) {
-            std::vector<int64_t> hm((size_t)B * T);
-            HIPCHK(c, hipStreamSynchronize(st));      // inputs ready (one-time, outside the token loop)
-            HIPCHK(c, hipMemcpy(hm.data(), emb_mask, hm.size() * 8, hipMemcpyDeviceToHost));
-            for (int i = 0; i < b; ++i) for (int t = 0; t < T; ++t) mk[(size_t)i * T + t] = hm[(size_t)row_img[(size_t)i] * T + t] != 0;
-        }
-        HIPCHK(c, hipMemcpyAsync(c->maskb.p, mk.data(), mk.size(), hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));          // mk is a stack-lifetime host buffer
-    }
-    int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 16;
-    {
-        int init[16] = {T, 0, T, 0, T, 0, T, 0, T, 0, T, 0, T, 0, T, 0};    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
-        HIPCHK(c, hipMemcpyAsync(pos, init, 64, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        for (int i = 0; i < 8; ++i) { c->h_init[2 * i] = T; c->h_init[2 * i + 1] = 0; }    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
+        HIPCHK(c, hipMemcpyAsync(pos, c->h_init, 64, hipMemcpyHostToDevice, st));
     }
 
     // ---- D. text prefix embed: cls_embedding.cap_proj (gpt_t2i.py:435), uncond rows = uncond_embedding (generate.py:157)
@@ -1021,7 +1012,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             car_launch_rmsnorm(mode, &np, rowsP, st);
         }
         { GemmP q = gp(xn, D, Wp(c, L + "attention.wqkv.weight"), D, qkv, 3 * D, (int)rowsP, 3 * D, D); car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
-        car_launch_prefill_rope_kv(mode, qkv, off(c->kv.p, (size_t)(2 * l) * kv_layer, e), off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e), c->rope, b, T, Hn, D, S_max, st);
+        if (fast) car_launch_prefill_rope_kv2(qkv, off(c->kv.p, (size_t)(2 * l) * kv_layer, e), off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e), c->rope, b, T, Hn, D, SA, st);
+        else car_launch_prefill_rope_kv(mode, qkv, off(c->kv.p, (size_t)(2 * l) * kv_layer, e), off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e), c->rope, b, T, Hn, D, S_max, st);
         {
             GemmP q = gp(qkv, 3 * D, off(qkv, (size_t)D, e), 3 * D, S, T, T, T, 64);
             q.alpha = 0.125f; q.out_f32 = 1; q.nb0 = b; q.nb1 = Hn;
@@ -1072,54 +1064,55 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     c->stats.graph_used = 0;
     Grp grp[8]; memset(grp, 0, sizeof(grp));
     if (fast) {
-        size_t tot = 0; size_t sizes[8][5];
+        // per-chain scratch from one arena: XP-packed xn / att [Mb*16, D], mid [Mb*16, Fh], q [bg, D] (bf16); logits [bg, V],
+        // split-KV partials (fp32).  Every slice is a multiple of 16 bytes.
+        size_t tot = 0; size_t sizes[8][6];
         for (int gi = 0; gi < NG; ++gi) {
             Grp& gr = grp[gi];
             gr.b0 = mult * img0[gi]; gr.bg = mult * (img0[gi + 1] - img0[gi]);
-            const int bg = gr.bg;
+            const int bg = gr.bg; const size_t M16 = rup((size_t)bg, 16);
             gr.nsplit = 1; { const int wg = bg * Hn; while (wg * gr.nsplit < 1024 && gr.nsplit < 16) gr.nsplit *= 2; }
-            FastBufs& f = gr.fb;
-            const bool f8 = g.decode_weight_fp8 != 0;
-            f.ksq = pick_ks(3 * D, D, bg, f8); f.kso = pick_ks(D, D, bg, f8); f.ks13 = pick_ks(2 * Fh, D, bg, f8); f.ks2 = pick_ks(D, Fh, bg, f8); f.ksl = pick_ks(V, D, bg, f8);
-            sizes[gi][0] = (size_t)f.ksq * bg * 3 * D; sizes[gi][1] = (size_t)f.kso * bg * D; sizes[gi][2] = (size_t)f.ks13 * bg * 2 * Fh;
-            sizes[gi][3] = (size_t)f.ks2 * bg * D; sizes[gi][4] = (size_t)f.ksl * bg * V;
-            for (int k = 0; k < 5; ++k) tot += sizes[gi][k];          // each a multiple of 4 floats (N % 4 == 0): 16-byte aligned slices
-            tot += rup((size_t)bg * Hn * gr.nsplit * 66, 4);
+            sizes[gi][0] = M16 * D * 2; sizes[gi][1] = M16 * D * 2; sizes[gi][2] = M16 * Fh * 2; sizes[gi][3] = rup((size_t)bg * D * 2, 16);
+            sizes[gi][4] = (size_t)bg * V * 4; sizes[gi][5] = rup((size_t)bg * Hn * gr.nsplit * 66 * 4, 16);
+            for (int k = 0; k < 6; ++k) tot += sizes[gi][k];
         }
-        NEED(c, c->dec_parts, tot * 4);
-        float* pbase = (float*)c->dec_parts.p;
+        NEED(c, c->dec_parts, tot);
+        char* pbase = (char*)c->dec_parts.p;
         for (int gi = 0; gi < NG; ++gi) {
             Grp& gr = grp[gi]; FastBufs& f = gr.fb;
-            f.pq = pbase; pbase += sizes[gi][0]; f.po = pbase; pbase += sizes[gi][1]; f.p13 = pbase; pbase += sizes[gi][2];
-            f.p2 = pbase; pbase += sizes[gi][3]; f.pl = pbase; pbase += sizes[gi][4];
-            gr.attn_part = pbase; pbase += rup((size_t)gr.bg * Hn * gr.nsplit * 66, 4);
-            gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: (pos, step) x 8 chains, then cur_tok
+            f.xn = (bf16_t*)pbase; pbase += sizes[gi][0]; f.att = (bf16_t*)pbase; pbase += sizes[gi][1]; f.mid = (bf16_t*)pbase; pbase += sizes[gi][2];
+            f.q = (bf16_t*)pbase; pbase += sizes[gi][3]; f.logits = (float*)pbase; pbase += sizes[gi][4]; f.attn_part = (float*)pbase; pbase += sizes[gi][5];
+            gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: (pos, step) x 8 chains, then cur_tok[b], then jmin[b]
             gr.sp = group_sampler(gi); gr.sp.step_ptr = gr.step;
-            gr.sp.logits = nullptr;     // set per launch to the group's logits partials
+            gr.sp.logits = nullptr;     // set per launch to the chain's logits
         }
     }
+    const unsigned char* fmask = emb_mask ? (const unsigned char*)c->maskb.p : nullptr;      // no text-pad mask: nothing to test per position
+    const int* fjmin = emb_mask ? jmin : nullptr;
     bool capturing = false;
     auto step_fn = [&]() {
         if (!fast) { enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st); return; }
         if (NG >= 2 && capturing) {      // fork NG-1 extra branches inside the capture
             (void)hipEventRecord(c->ev_fork, st);
             for (int gi = 1; gi < NG; ++gi) (void)hipStreamWaitEvent(c->streamx[gi - 1], c->ev_fork, 0);
-            enqueue_decode_step_fast(c, sb, grp[0], b, S_max, n_tok, use_control != 0, cs, st);
+            enqueue_decode_step_fast(c, sb, grp[0], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, st);
             for (int gi = 1; gi < NG; ++gi) {
-                enqueue_decode_step_fast(c, sb, grp[gi], b, S_max, n_tok, use_control != 0, cs, c->streamx[gi - 1]);
+                enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, c->streamx[gi - 1]);
                 (void)hipEventRecord(c->ev_joinx[gi - 1], c->streamx[gi - 1]); (void)hipStreamWaitEvent(st, c->ev_joinx[gi - 1], 0);
             }
         } else {
-            for (int gi = 0; gi < NG; ++gi) enqueue_decode_step_fast(c, sb, grp[gi], b, S_max, n_tok, use_control != 0, cs, st);
+            for (int gi = 0; gi < NG; ++gi) enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, st);
         }
         c->n_dec_kernels *= NG;
     };
     if (nsteps > 0) {
         char keyb[512];
-        snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%p|%p", b, B, S_max, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
-                 c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval * 4 + NG, (const void*)forced_tokens, (void*)logits_out);
-        { char kb2[200]; snprintf(kb2, sizeof(kb2), "|%d|%g|%d|%g|%llu|gen%llu|%p|%p|%p", sp->sample_logits, (double)sp->temperature, sp->top_k, (double)sp->top_p,
-                                   (unsigned long long)sp->seed, g_alloc_gen, xn, att, mid); strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
+        // every scalar and pointer that the captured kernels bake in (n_new: the sampler's row stride and per-chain offsets)
+        snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%d|%d|%p|%p", b, B, S_max, n_new, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
+                 c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
+                 (const void*)forced_tokens, (void*)logits_out);
+        { char kb2[200]; snprintf(kb2, sizeof(kb2), "|%d|%g|%d|%g|%llu|gen%llu|%p|%p|%p|%p", sp->sample_logits, (double)sp->temperature, sp->top_k, (double)sp->top_p,
+                                   (unsigned long long)sp->seed, g_alloc_gen, xn, att, mid, c->scal.p); strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
         bool graph_ok = true;
         if (getenv("CAR_NO_GRAPH")) { /* skip capture */ }
@@ -1147,17 +1140,15 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     HIPCHK(c, hipMemcpyAsync(out_tokens, c->tok_out.p, (size_t)B * n_new * 4, hipMemcpyDeviceToDevice, st));
     fence_out(c, caller);
     HIPCHK(c, hipGetLastError());
-    // stats (algorithmic bytes: DESIGN.md §4 / SURVEY.md §8d)
+    // stats inputs (algorithmic bytes are computed in car_get_stats, which synchronises anyway: DESIGN.md §4 / SURVEY.md §8d)
     {
         c->stats.decode_steps = nsteps;
         c->stats.decode_kernels_per_step = c->n_dec_kernels;
         const double we = (mode == CAR_BF16 && g.decode_weight_fp8) ? 1.0 : (double)e;      // fp8 decode weights: 1 B/param (+ fp32 row scales)
-        const double wbytes = ((double)g.n_layer * ((double)3 * D * D + (double)D * D + 3.0 * (double)Fh * D) + (double)V * D) * we
-                              + ((double)g.n_layer * 2.0 * D + D) * (double)e
-                              + ((mode == CAR_BF16 && g.decode_weight_fp8) ? 4.0 * ((double)g.n_layer * (5.0 * D + 2.0 * Fh) + V) : 0.0);
-        double kvb = 0;
-        for (int i = 0; i < nsteps; ++i) { const double p = T + i; kvb += 2.0 * g.n_layer * D * (double)e * (p + 1); }
-        c->stats.decode_algo_bytes = (int64_t)(wbytes * nsteps + kvb * b);
+        c->st_wbytes = ((double)g.n_layer * ((double)3 * D * D + (double)D * D + 3.0 * (double)Fh * D) + (double)V * D) * we
+                       + ((double)g.n_layer * 2.0 * D + D) * (double)e
+                       + ((mode == CAR_BF16 && g.decode_weight_fp8) ? 4.0 * ((double)g.n_layer * (5.0 * D + 2.0 * Fh) + V) : 0.0);
+        c->st_b = b; c->st_T = T; c->st_nsteps = nsteps; c->st_has_mask = emb_mask ? 1 : 0; c->st_jmin = jmin;
     }
     return 0;
 }
@@ -1191,6 +1182,17 @@ extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
     (void)hipEventSynchronize(c->ev_t2);
     if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) == hipSuccess) c->stats.prefill_ms = ms; else (void)hipGetLastError();
     if (hipEventElapsedTime(&ms, c->ev_t1, c->ev_t2) == hipSuccess) c->stats.decode_ms = ms; else (void)hipGetLastError();
+    {
+        // algorithmic bytes of the decode loop: weights once per step for the whole batch + the KV rows a step has to read:
+        // positions [first attendable text position, p] of every sequence (text-pad rows are masked and skipped, never fetched)
+        const car_config& g = c->cfg;
+        std::vector<int> jm((size_t)(c->st_b > 0 ? c->st_b : 1), 0);
+        if (c->st_has_mask && c->st_jmin && c->st_b > 0) { (void)hipStreamSynchronize(c->stream); if (hipMemcpy(jm.data(), c->st_jmin, (size_t)c->st_b * 4, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError(); }
+        double kvb = 0;
+        for (int s = 0; s < c->st_b; ++s)
+            for (int i = 0; i < c->st_nsteps; ++i) { const double p = c->st_T + i; kvb += 2.0 * g.n_layer * g.dim * (double)c->esz * (p + 1 - jm[(size_t)s]); }
+        c->stats.decode_algo_bytes = (int64_t)(c->st_wbytes * c->st_nsteps + kvb);
+    }
     *out = c->stats;
     return 0;
 }

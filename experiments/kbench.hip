@@ -102,7 +102,7 @@ static void test_gemm() {
 }
 
 // ------------------------------------------------------------------------------------------------ QKV epilogue + attention
-struct AttnCase { int b, H, T, pos, nsplit, packed_out, maskmode; };
+struct AttnCase { int b, H, T, pos, nsplit, packed_out, maskmode, variant; };
 
 static void test_qkv_attn(const AttnCase& c) {
     const int b = c.b, H = c.H, dim = H * 64, K = 96, T = c.T, pos = c.pos, S_max = ((pos + 1 + 7) / 8) * 8, SA = (S_max + 31) / 32 * 32;
@@ -128,7 +128,7 @@ static void test_qkv_attn(const AttnCase& c) {
     // reference: qkv = rnd(X W^T); rope; cache write; attention in fp64 over valid positions
     std::vector<float> qkv((size_t)b * 3 * dim);
     for (int i = 0; i < b; ++i) for (int n = 0; n < 3 * dim; ++n) { double s = 0; for (int k = 0; k < K; ++k) s += (double)X[(size_t)i * K + k] * W[(size_t)n * K + k]; qkv[(size_t)i * 3 * dim + n] = rb((float)s); }
-    std::vector<float> qr((size_t)b * dim), kr((size_t)b * dim), want((size_t)b * dim);
+    std::vector<float> qr((size_t)b * dim), kr((size_t)b * dim), want((size_t)b * dim), want_nm((size_t)b * dim);
     for (int i = 0; i < b; ++i) for (int h = 0; h < H; ++h) {
         for (int pr = 0; pr < 32; ++pr) {
             const float cs = rope[((size_t)pos * 32 + pr) * 2], sn = rope[((size_t)pos * 32 + pr) * 2 + 1];
@@ -149,6 +149,13 @@ static void test_qkv_attn(const AttnCase& c) {
             for (int d = 0; d < 64; ++d) { const float vv = p < pos ? Vh[(((size_t)i * H + h) * pos + p) * 64 + d] : qkv[(size_t)i * 3 * dim + 2 * dim + h * 64 + d]; o[d] += w * vv; }
         }
         for (int d = 0; d < 64; ++d) want[(size_t)i * dim + h * 64 + d] = (float)(o[d] / L);
+        {   // diagnosis only: the same without the text-pad mask
+            double mx2 = -1e300; std::vector<double> s2(pos + 1);
+            for (int p = 0; p <= pos; ++p) { double a = 0; for (int d = 0; d < 64; ++d) { const float kk = p < pos ? Kh[(((size_t)i * H + h) * pos + p) * 64 + d] : kr[(size_t)i * dim + h * 64 + d]; a += (double)qr[(size_t)i * dim + h * 64 + d] * kk; } s2[p] = a * 0.125; mx2 = std::max(mx2, s2[p]); }
+            double L2 = 0; std::vector<double> o2(64, 0.0);
+            for (int p = 0; p <= pos; ++p) { const double w = exp(s2[p] - mx2); L2 += w; for (int d = 0; d < 64; ++d) { const float vv = p < pos ? Vh[(((size_t)i * H + h) * pos + p) * 64 + d] : qkv[(size_t)i * 3 * dim + 2 * dim + h * 64 + d]; o2[d] += w * vv; } }
+            for (int d = 0; d < 64; ++d) want_nm[(size_t)i * dim + h * 64 + d] = (float)(o2[d] / L2);
+        }
     }
     auto xp = pack_rows(X, b, K), wp = pack_rows(W, 3 * dim, K);
     bf16_t* dX = dalloc<bf16_t>(xp.size()); h2d(dX, xp);
@@ -167,7 +174,9 @@ static void test_qkv_attn(const AttnCase& c) {
     if (car_launch_dec_gemm_cfg(&g, EPI_QKV, cfg, 0)) { printf("qkv cfg rejected\n"); ++g_fail; }
     Attn2P a; memset(&a, 0, sizeof(a)); a.q = dQ; a.kc = dK; a.vc = dV; a.pos = dPos; a.mask = c.maskmode ? dM : nullptr; a.out = dO; a.part = dPart;
     a.H = H; a.SA = SA; a.T = T; a.dim = dim; a.nsplit = c.nsplit; a.out_packed = c.packed_out;
-    car_launch_dec_attn2(&a, b, 0);
+    int* dJ = dalloc<int>(b);
+    if (c.maskmode && (c.variant % 2 == 0 || c.variant == 41)) { car_launch_mask_first_valid(dM, dJ, b, T, 0); a.jmin = dJ; }     // both jmin sources get exercised
+    car_launch_dec_attn2_var(&a, b, c.variant, 0);
     CK(hipDeviceSynchronize());
     // cache rows written by the epilogue
     auto kc2 = d2h(dK, kc.size()), vc2 = d2h(dV, vc.size()); auto q2 = d2h(dQ, (size_t)b * dim);
@@ -188,9 +197,18 @@ static void test_qkv_attn(const AttnCase& c) {
         const float got = bf2f(o[c.packed_out ? xp_off(i, k, dim) : (size_t)i * dim + k]);
         e = std::max(e, std::fabs((double)got - want[(size_t)i * dim + k]));
     }
-    snprintf(nm, sizeof(nm), "dec_attn2 b=%d H=%d T=%d pos=%d nsplit=%d packed=%d mask=%d", b, H, T, pos, c.nsplit, c.packed_out, c.maskmode);
+    snprintf(nm, sizeof(nm), "dec_attn2<%d> b=%d H=%d T=%d pos=%d nsplit=%d packed=%d mask=%d", c.variant, b, H, T, pos, c.nsplit, c.packed_out, c.maskmode);
     report(nm, e, 0.02);
-    for (void* p : {(void*)dX, (void*)dW, (void*)dK, (void*)dV, (void*)dR, (void*)dM, (void*)dPos, (void*)dQ, (void*)dO, (void*)dPart}) CK(hipFree(p));
+    if (e > 0.02) {
+        for (int i = 0; i < b && i < 4; ++i) for (int h = 0; h < H; ++h) {
+            double ei = 0, en = 0;
+            for (int d = 0; d < 64; ++d) { const int k = h * 64 + d; const float got = bf2f(o[c.packed_out ? xp_off(i, k, dim) : (size_t)i * dim + k]);
+                ei = std::max(ei, std::fabs((double)got - want[(size_t)i * dim + k])); en = std::max(en, std::fabs((double)got - want_nm[(size_t)i * dim + k])); }
+            int first = T; for (int t = 0; t < T; ++t) if (mask[(size_t)i * T + t]) { first = t; break; }
+            printf("    seq %d head %d: err vs masked ref %.3e, vs unmasked ref %.3e (first valid text pos %d)\n", i, h, ei, en, first);
+        }
+    }
+    for (void* p : {(void*)dX, (void*)dW, (void*)dK, (void*)dV, (void*)dR, (void*)dM, (void*)dPos, (void*)dQ, (void*)dO, (void*)dPart, (void*)dJ}) CK(hipFree(p));
 }
 
 // ------------------------------------------------------------------------------------------------ rmsnorm2
@@ -296,15 +314,21 @@ static void bench_attn(bool quick) {
     unsigned char* dM = dalloc<unsigned char>(mask.size()); h2d(dM, mask);
     int* dPos = dalloc<int>(1);
     CK(hipDeviceSynchronize());
+    int* dJ = dalloc<int>(256); car_launch_mask_first_valid(dM, dJ, 256, T, 0);
     for (const C& c : cs) for (int pos : {127, 631, 1143}) {
         CK(hipMemcpy(dPos, &pos, 4, hipMemcpyHostToDevice));
-        Attn2P a; memset(&a, 0, sizeof(a)); a.q = dQ; a.pos = dPos; a.mask = dM; a.out = dO; a.part = dPart; a.H = H; a.SA = SA; a.T = T; a.dim = dim; a.nsplit = c.nsplit; a.out_packed = 1;
-        const float us = time_launches(quick ? 30 : 60, [&](int it) { Attn2P q = a; q.kc = dKV + per * 2 * (it % NLAY); q.vc = q.kc + per; car_launch_dec_attn2(&q, c.b, 0); });
         double rows = 0; for (int i = 0; i < c.b; ++i) { const int L = 8 + (i * 13) % 33; rows += pos + 1 - (T - L); }
         const double bytes = rows * H * 256.0;
-        printf("ATTN b=%-3d nsplit=%-2d pos=%-4d  %.2f us   %.1f MB read (valid rows only)  %.2f TB/s\n", c.b, c.nsplit, pos, us, bytes / 1e6, bytes / 1e6 / us);
-        fflush(stdout);
+        printf("ATTN b=%-3d nsplit=%-2d pos=%-4d %.1f MB (valid rows) |", c.b, c.nsplit, pos, bytes / 1e6);
+        for (int variant : {41, 40, 21, 20, 141}) {
+            Attn2P a; memset(&a, 0, sizeof(a)); a.q = dQ; a.pos = dPos; a.mask = dM; a.out = dO; a.part = dPart; a.H = H; a.SA = SA; a.T = T; a.dim = dim; a.nsplit = c.nsplit; a.out_packed = 1;
+            a.jmin = variant == 141 ? nullptr : dJ;             // 141: variant 41 with the in-kernel mask scan
+            const float us = time_launches(quick ? 30 : 60, [&](int it) { Attn2P q = a; q.kc = dKV + per * 2 * (it % NLAY); q.vc = q.kc + per; car_launch_dec_attn2_var(&q, c.b, variant % 100, 0); });
+            printf("  v%d: %.1f us %.2f TB/s", variant, us, bytes / 1e6 / us);
+        }
+        printf("\n"); fflush(stdout);
     }
+    CK(hipFree(dJ));
     (void)S_max;
     for (void* q : {(void*)dKV, (void*)dQ, (void*)dO, (void*)dPart, (void*)dM, (void*)dPos}) CK(hipFree(q));
 }
@@ -315,10 +339,10 @@ int main(int argc, char** argv) {
     test_gemm();
     test_norm();
     const AttnCase cases[] = {
-        {3, 2, 40, 40, 1, 0, 1}, {3, 2, 40, 63, 1, 1, 1}, {3, 2, 40, 64, 1, 1, 1}, {3, 2, 40, 250, 1, 1, 1}, {3, 2, 40, 250, 4, 1, 1}, {20, 2, 40, 131, 2, 0, 1},
-        {3, 2, 40, 97, 1, 1, 2}, {3, 2, 40, 97, 4, 1, 2}, {2, 1, 1, 1, 1, 1, 0}, {2, 1, 1, 33, 16, 1, 0}, {17, 3, 120, 600, 1, 1, 1},
+        {3, 2, 40, 40, 1, 0, 1, 0}, {3, 2, 40, 63, 1, 1, 1, 0}, {3, 2, 40, 64, 1, 1, 1, 0}, {3, 2, 40, 250, 1, 1, 1, 0}, {3, 2, 40, 250, 4, 1, 1, 0}, {20, 2, 40, 131, 2, 0, 1, 0},
+        {3, 2, 40, 97, 1, 1, 2, 0}, {3, 2, 40, 97, 4, 1, 2, 0}, {2, 1, 1, 1, 1, 1, 0, 0}, {2, 1, 1, 33, 16, 1, 0, 0}, {17, 3, 120, 600, 1, 1, 1, 0}, {5, 2, 120, 1143, 1, 1, 1, 0},
     };
-    for (const auto& c : cases) test_qkv_attn(c);
+    for (int variant : {41, 40, 21, 20}) for (auto c : cases) { c.variant = variant; test_qkv_attn(c); }
     printf("== correctness: %d failure(s)\n", g_fail);
     fflush(stdout);
     if (!noperf) { bench_attn(quick); bench_gemm(quick); }

@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = os.environ.get("CONTROLAR_REFERENCE", "/root/reference")
+OUT = os.environ.get("CONTROLAR_GOLDEN_OUT", HERE)       # where fixtures are written (tests regenerate into a temp dir)
 sys.path.insert(0, REF)
 
 import transformers  # noqa: E402
@@ -71,7 +72,11 @@ def build_ref_vq(cfg: C.VQConfig, sd):
                                         codebook_embed_dim=cfg.codebook_embed_dim,
                                         decoder_ch_mult=list(cfg.ch_mult), z_channels=cfg.z_channels))
     if cfg.ch != 128:
+        # tiny test architecture: the reference's ModelArgs has no `ch` knob, so both halves are rebuilt at the test width
+        # (synth.vq_state_dict emits encoder.* / quant_conv.* since car_vq_encode exists; strict=False only forgives the buffers)
         m.decoder = ref_vq.Decoder(ch_mult=list(cfg.ch_mult), z_channels=cfg.z_channels, ch=cfg.ch,
+                                   num_res_blocks=cfg.num_res_blocks)
+        m.encoder = ref_vq.Encoder(ch_mult=list(cfg.ch_mult), z_channels=cfg.z_channels, ch=cfg.ch,
                                    num_res_blocks=cfg.num_res_blocks)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert all(k.startswith(("encoder.", "quant_conv.", "quantize.codebook_used")) for k in missing), missing
@@ -138,7 +143,7 @@ def run_case(name, cfg: C.PathConfig, B, H, W, cfg_scale, control_strength=1.0, 
         with torch.no_grad():
             px = vqm.decode_code(toks, [B, cfg.vq.codebook_embed_dim, H // 16, W // 16])
         out["pixels"] = px.numpy().astype(np.float32)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: {time.time()-t0:.1f}s distinct={len(np.unique(out['tokens']))} "
           f"min_margin={margin.min():.4g} med_margin={margin.median():.3g} -> {os.path.getsize(path)/1e3:.0f} KB")
@@ -153,8 +158,25 @@ def case_vq16_real(name="vq16_real_8x8"):
     toks = torch.randint(0, cfg.codebook_size, (2, 64), generator=g, dtype=torch.int32)
     with torch.no_grad():
         px = m.decode_code(toks, [2, 8, 8, 8])
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), tokens=toks.numpy(), pixels=px.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), tokens=toks.numpy(), pixels=px.numpy())
     print(name, px.shape, float(px.abs().max()), float(px.abs().mean()))
+
+
+def case_vq16_real_512(name="vq16_real_32x32"):
+    """The real VQ-16 decoder at the bench's size: 32x32 tokens -> 512x512 pixels (vq_model.py:53-56,174-195).  The fixture
+    keeps a strided pixel lattice plus two dense patches (image corner and centre) so that tiling/chunking errors show."""
+    cfg = C.VQConfig()
+    sd = synth.vq_state_dict(cfg, seed=2)
+    m = build_ref_vq(cfg, sd)
+    g = torch.Generator().manual_seed(9)
+    toks = torch.randint(0, cfg.codebook_size, (2, 1024), generator=g, dtype=torch.int32)
+    with torch.no_grad():
+        px = m.decode_code(toks, [2, 8, 32, 32])
+    px = px.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), tokens=toks.numpy(), lattice=px[:, :, ::8, ::8].copy(),
+                        corner=px[:, :, :24, :24].copy(), centre=px[:, :, 244:268, 244:268].copy(),
+                        stats=np.array([np.abs(px).max(), np.abs(px).mean()], dtype=np.float32))
+    print(name, px.shape, float(np.abs(px).max()), float(np.abs(px).mean()))
 
 
 CASES = {
@@ -179,6 +201,7 @@ CASES = {
     "tiny_mask_edges": lambda: run_case("tiny_mask_edges", C.tiny_t2i(64, "canny"), 3, 128, 128, 1.5, vq=False, lengths=[1, 120, 40]),
     "tiny_no_mask": lambda: run_case("tiny_no_mask", C.tiny_t2i(64, "canny"), 2, 128, 128, 1.0, vq=False, no_mask=True),
     "vq16_real_8x8": case_vq16_real,
+    "vq16_real_32x32": case_vq16_real_512,
     # GPT-B sized, 256 tokens
     "b_canny_256_cfg4": lambda: run_case("b_canny_256_cfg4", C.b_t2i(256, "small", "canny"), 1, 256, 256, 4.0,
                                          vq=False, keep_logits=16),
@@ -231,7 +254,7 @@ def case_bf16_calibration(base="xl_canny_512_cfg1", mk=lambda: C.xl_t2i(1024, "s
     sub = lg[:, steps][:, :, ::4].numpy().astype(np.float32)
     d = np.abs(sub - gold["logits"])
     agree = (lg.argmax(-1).numpy() == gold["tokens"])
-    np.savez_compressed(os.path.join(HERE, base + "_refbf16.npz"), ref_bf16_max=np.float32(d.max()), ref_bf16_mean=np.float32(d.mean()),
+    np.savez_compressed(os.path.join(OUT, base + "_refbf16.npz"), ref_bf16_max=np.float32(d.max()), ref_bf16_mean=np.float32(d.mean()),
                         ref_bf16_agree=np.float32(agree.mean()), threads=np.int64(threads))
     print(f"{base}: reference bf16 vs fp32 teacher-forced: max|d|={d.max():.4f} mean|d|={d.mean():.4f} argmax agree={agree.mean():.4f} ({time.time()-t0:.0f}s)")
 
@@ -281,11 +304,11 @@ def run_c2i(name, cfg, imgs_u8, labels, cfg_scale, threads=8, seed=0):
     logits = torch.stack(tap.rows, dim=1)
     top2 = logits.topk(2, dim=-1).values
     st = 1 if logits.shape[1] * logits.shape[2] <= 64 * 1024 else 8      # big cases keep every 8th step / 4th vocab entry
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), tokens=toks.numpy().astype(np.int32),
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), tokens=toks.numpy().astype(np.int32),
                         logits=logits.numpy()[:, ::st, ::(2 if st == 1 else 4)].astype(np.float16), logits_step_stride=np.int64(st),
                         margin=(top2[..., 0] - top2[..., 1]).numpy().astype(np.float32), images_u8=imgs_u8, labels=labels,
                         cfg_scale=np.float32(cfg_scale), meta=np.array([x.shape[0], x.shape[2], x.shape[3], seed, threads], dtype=np.int64))
-    print(f"{name}: distinct={len(np.unique(toks.numpy()))} ref bf16 -> {os.path.getsize(os.path.join(HERE, name + '.npz'))/1e3:.0f} KB")
+    print(f"{name}: distinct={len(np.unique(toks.numpy()))} ref bf16 -> {os.path.getsize(os.path.join(OUT, name + '.npz'))/1e3:.0f} KB")
 
 
 def case_c2i_tiny():
@@ -325,7 +348,7 @@ def case_vq_encode(name, cfg, H, W, seed=2):
     with torch.no_grad():
         quant, _, info = m.encode(img)
     idx = info[2].view(2, -1)
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), tokens=idx.numpy().astype(np.int32), meta=np.array([2, H, W, seed], dtype=np.int64))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), tokens=idx.numpy().astype(np.int32), meta=np.array([2, H, W, seed], dtype=np.int64))
     print(name, idx.shape, "distinct", len(np.unique(idx.numpy())))
 
 

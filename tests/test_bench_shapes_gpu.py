@@ -1,0 +1,132 @@
+"""GPU parity at the shapes bench.py times (pytest -m gpu): the headline configuration decodes a few hundred sequences per GPU
+as concurrent chains of M >= 96 rows through dec_gemm / dec_attn2 (controlar_amd/csrc/decode2.hip) over S_max = 1144 caches,
+and decodes 512x512 images in batch chunks — none of which the B = 1 / tiny-graph cases reach.
+
+  * XL, bf16, B = 192 (two chains of 96), 1024 tokens, teacher-forced on the reference's fp32 tokens: the golden image sits in
+    row 0 (chain 0) and row 100 (chain 1); both must stay within the tolerance calibrated on the reference's own bf16 path
+    (tests/golden/xl_canny_512_cfg1_refbf16.npz x 1.5) and must equal each other bit for bit (same arithmetic, other chain).
+  * XL + DINOv2-base, depth (bicubic), cfg 4, B = 64 (BASELINE config 3: one chain of 128 rows) against oracle steps.
+  * the real VQ-16 decoder at 32x32 tokens -> 512x512 against pixels minted by the reference, in a batch that spans chunks.
+  * re-using one context with a different n_new (graph cache key) and B >= 2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.cases import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_xl_two_chains_teacher_forced_at_bench_shape():
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    gold = dict(np.load(os.path.join(GOLDEN, "xl_canny_512_cfg1.npz")))
+    cal = np.load(os.path.join(GOLDEN, "xl_canny_512_cfg1_refbf16.npz"))
+    _, H, W, seed, _ = [int(x) for x in gold["meta"]]
+    cfg = C.xl_t2i(1024, "small", "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=seed)
+    B, n_new, twin = 192, 1024, 100
+    img = synth.canny_like_control(B, H, W).to(torch.bfloat16)            # row 0 = the golden image (seed 1234 + 0)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    img[twin], emb[twin], mask[twin] = img[0], emb[0], mask[0]
+    forced = torch.from_numpy(gold["tokens"]).repeat(B, 1)
+    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    toks, logits = eng.generate(emb.to(torch.bfloat16).cuda(), n_new, mask.cuda(), cfg_scale=1.0, forced_tokens=forced, return_logits=True)
+    st = eng.stats()
+    assert st["graph_used"] and st["decode_kernels_per_step"] <= 2 * 300, st           # two chains, <= 300 kernel nodes each
+    steps = torch.from_numpy(gold["logits_steps"]).cuda()
+    rows = logits[[0, twin]][:, steps][:, :, ::4].float().cpu().numpy()
+    full0, full1 = logits[0].cpu(), logits[twin].cpu()
+    tk = toks[[0, twin]].cpu().numpy()
+    assert torch.isfinite(logits[:, ::64]).all()
+    eng.close()
+    assert torch.equal(full0, full1), f"chain 0 and chain 1 disagree on identical inputs: max|d| {float((full0 - full1).abs().max())}"
+    for r in range(2):
+        d = np.abs(rows[r] - gold["logits"][0])
+        assert d.max() <= 1.5 * float(cal["ref_bf16_max"]) and d.mean() <= 1.5 * float(cal["ref_bf16_mean"]), (r, d.max(), d.mean())
+        agree = tk[r] == gold["tokens"][0]
+        assert agree.mean() >= float(cal["ref_bf16_agree"]) - 0.03, (r, agree.mean())
+        assert agree[gold["margin"][0] > 2.0 * float(cal["ref_bf16_max"])].all()
+
+
+def test_xl_base_depth_cfg4_b64_vs_oracle_steps():
+    """BASELINE config 3 shapes: DINOv2-base (bicubic resize), cfg 4 -> one chain of 128 rows [cond | uncond]."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    from oracle import controlar_oracle as O
+    cfg = C.xl_t2i(1024, "base", "depth")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    B, H, W, n_chk, s_ = 64, 512, 512, 8, 4.0
+    img = synth.smooth_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    # the oracle decodes images independently: check two of them (first and one in the middle of the batch)
+    sel = [0, 37]
+    toks_o, logits_o = O.generate(gsd, cfg, emb[sel], n_chk, mask[sel], cfg_scale=s_, condition=img[sel], control_strength=0.6, return_logits=True)
+    forced = torch.zeros(B, n_chk, dtype=torch.int32); forced[:] = toks_o[0]; forced[sel[1]] = toks_o[1]
+    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    a = eng.encode_control(img.cuda(), want_output=True)[sel].float().cpu()
+    ref_a = O.mlp(O.control_encoder(gsd, cfg, img[sel]), gsd["adapter_mlp.fc1.weight"], gsd["adapter_mlp.fc2.weight"])
+    da = (a - ref_a).abs()
+    print(f"adapter(base, bicubic) bf16 vs fp32 oracle: max|d| {float(da.max()):.4f} mean|d| {float(da.mean()):.5f}; |ref| max {float(ref_a.abs().max()):.3f} mean {float(ref_a.abs().mean()):.4f}")
+    assert float(da.mean()) <= 0.05 * float(ref_a.abs().mean()) and float(da.max()) <= 0.25 * float(ref_a.abs().max())   # bf16 DINOv2-base (12 layers) + adapter MLP vs fp32
+    toks, logits = eng.generate(emb.cuda(), n_chk, mask.cuda(), cfg_scale=s_, control_strength=0.6, forced_tokens=forced, return_logits=True)
+    d = (logits[sel].cpu() - logits_o).abs()
+    cal = np.load(os.path.join(GOLDEN, "xl_canny_512_cfg1_refbf16.npz"))
+    k = float(np.sqrt(s_ ** 2 + (s_ - 1) ** 2))                  # the CFG mix u + (c-u)*s weighs single-pass errors by s and s-1
+    assert float(d.max()) <= 1.5 * float(cal["ref_bf16_max"]) * k and float(d.mean()) <= 1.5 * float(cal["ref_bf16_mean"]) * k, (float(d.max()), float(d.mean()))
+    top2 = logits_o.topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 2.0 * float(cal["ref_bf16_max"]) * k
+    assert bool((toks[sel].cpu() == toks_o)[safe].all())
+    eng.close()
+
+
+@pytest.mark.parametrize("prec,B,atol,mtol", [("bf16", 33, 0.6, 0.04), ("fp32", 17, 2e-3, 1e-4)])
+def test_vq16_real_512_in_batch_chunks(prec, B, atol, mtol):
+    """32x32 tokens -> 512x512 pixels through the real VQ-16 decoder; B is one more than the activation-chunk size
+    (engine.hip car_vq_decode: 32 images in bf16, 15-16 in fp32), the golden tokens sit in the first and the last chunk."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    gold = np.load(os.path.join(GOLDEN, "vq16_real_32x32.npz"))
+    cfg = C.tiny_t2i(64, "canny"); cfg.vq = C.VQConfig()
+    eng = Engine(cfg, prec)
+    eng.load_state_dict(synth.vq_state_dict(cfg.vq, seed=2), finalize=True)
+    g = torch.Generator().manual_seed(21)
+    toks = torch.randint(0, cfg.vq.codebook_size, (B, 1024), generator=g, dtype=torch.int32)
+    toks[0] = torch.from_numpy(gold["tokens"][0]); toks[B - 1] = torch.from_numpy(gold["tokens"][1])
+    px = eng.vq_decode(toks, 32, 32)
+    assert bool(torch.isfinite(px).all())
+    for row, gi in ((0, 0), (B - 1, 1)):
+        p = px[row].cpu().numpy()
+        for name, got in (("lattice", p[:, ::8, ::8]), ("corner", p[:, :24, :24]), ("centre", p[:, 244:268, 244:268])):
+            d = np.abs(got - gold[name][gi])
+            assert d.max() <= atol and d.mean() <= mtol, (prec, row, name, d.max(), d.mean())
+    eng.close()
+
+
+def test_graph_cache_distinguishes_n_new():
+    """Two generate calls on one context with the same B and control but different n_new in the same S_max bucket (64 then 60):
+    the second must not replay the first call's graph (the sampler's row stride n_new is baked into it)."""
+    from tests.cases import load_case
+    from controlar_amd.engine import Engine
+    cs = load_case("tiny_canny_cfg1")
+
+    def fresh(n):
+        e = Engine(cs["cfg"], "bf16"); e.load_state_dict(cs["gsd"]); e.finalize()
+        e.encode_control(cs["img"].cuda())
+        t = e.generate(cs["emb"].cuda(), n, cs["mask"].cuda(), cfg_scale=1.0).cpu()
+        e.close()
+        return t
+    want64, want60 = fresh(64), fresh(60)
+    eng = Engine(cs["cfg"], "bf16"); eng.load_state_dict(cs["gsd"]); eng.finalize()
+    eng.encode_control(cs["img"].cuda())
+    got64 = eng.generate(cs["emb"].cuda(), 64, cs["mask"].cuda(), cfg_scale=1.0).cpu()
+    got60 = eng.generate(cs["emb"].cuda(), 60, cs["mask"].cuda(), cfg_scale=1.0).cpu()
+    eng.close()
+    assert cs["B"] >= 2
+    assert torch.equal(got64, want64) and torch.equal(got60, want60)
+    assert torch.equal(got60, want64[:, :60])
