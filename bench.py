@@ -232,20 +232,20 @@ def main():
         parity["golden_token_agreement"] = float((mine == gold).mean())
         assert parity["golden_prefix_tokens"] >= 2, parity
 
-    # (round-1 model, kept for reference only; superseded by measured_traffic() below)
-    # HBM-side traffic of one decode step from PMC (profiles/r01_pmc_FETCH_SIZE_b256.txt: rocprofv3 --pmc FETCH_SIZE on
-    # tools/pmc_workload.py, XL, chains of 64; FETCH_SIZE is in KiB and is doubled as MI355X_MICROARCH.md §HBM prescribes for
-    # wide coalesced reads on gfx950).  Per chain of 64 sequences and per layer: w13 19.76 + w2 12.94 + wqkv 11.24 + wo 4.68 +
-    # 2 x rmsnorm 4.25 + swiglu 7.43 MB = 64.55 MB (algorithmic weights: 40.6 MB; the rest is split-K partial re-reads);
-    # per step: + final norm 4.25 + logits 43.4 + sampler 16.8 MB.  dec_attn fetched 12.4 MB at positions 120-124 against
-    # 11.9 MB algorithmic (ratio 1.04), so KV traffic is taken as algorithmic x 1.04.  WRITE_SIZE could not be collected
-    # (the pass did not finish in the GPU budget): the write side is NOT included.
-    def pmc_traffic_per_step(b, kv_bytes_per_step):
-        if args.model != "xl" or args.precision != "bf16":
-            return None
-        chains = 1 if b < 48 else (2 if b <= 64 else min(8, (b + 63) // 64))       # engine.hip generate_impl: chains of <= 64 rows
-        per_chain = (36 * 64.55e6 + 4.25e6 + 43.4e6 + 16.8e6) * (min(b / chains, 64) / 64 * 0.37 + 0.63)   # partial traffic scales with rows, weights do not
-        return chains * per_chain + 1.04 * kv_bytes_per_step
+    # HBM traffic of one decode step (read + write) is taken from the committed PMC summary of the SAME configuration
+    # (profiles/pmc_decode_step.json, written by tools/pmc_decode.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    # passes, gfx950 corrections of MI355X_MICROARCH.md §HBM applied there); any other configuration reports null.
+    def measured_traffic():
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_decode_step.json")))
+        except Exception:
+            return None, "no PMC summary for this configuration"
+        same = (rec.get("model") == args.model and rec.get("batch") == args.batch and abs(rec.get("cfg_scale", 1.0) - args.cfg_scale) < 1e-6
+                and rec.get("precision") == args.precision and bool(rec.get("weights_fp8")) == bool(args.weights_fp8)
+                and rec.get("image_hw") == [Hh, Ww] and rec.get("adapter_size") == args.adapter_size)
+        if not same:
+            return None, "no PMC summary for this configuration"
+        return rec["fetch_bytes_per_step"] + rec["write_bytes_per_step"], rec.get("note", "")
 
     if rank == 0:
         value = G * args.steps / elapsed
@@ -266,14 +266,13 @@ def main():
                        "input_broadcast_s": t_bcast, "graph": st["graph_used"],
                        "decode_kernels_per_step": st["decode_kernels_per_step"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": pmc_traffic_per_step(args.batch * (2 if args.cfg_scale > 1.0 else 1),
-                                                         st["decode_algo_bytes"] / max(st["decode_steps"], 1) - 1.505e9),
-                         "traffic_note": "read side only, from profiles/r01_pmc_FETCH_SIZE_b256.txt (FETCH_SIZE KiB x 2, gfx950 correction), "
-                                         "scaled to this batch; WRITE_SIZE not collected",
+                         "traffic": measured_traffic()[0], "traffic_note": measured_traffic()[1],
                          "kernel": "decode step (one hipGraph replay = one token for all sequences)",
                          "bytes_per_launch": st["decode_algo_bytes"] / max(st["decode_steps"], 1),
                          "avg_launch_ms": per_step_ms},
         }
+        if parity:
+            out["config"]["self_check"] = parity
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, gsd, vsd, Hh, Ww, args.cpu_tokens)
         print(json.dumps(out), flush=True)

@@ -97,7 +97,10 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 #pragma unroll
         for (int j = 0; j < J; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const u32x4 zw = (u32x4){0u, 0u, 0u, 0u};
-    u32x4 wa[I], xa[J * XPU], wb[I], xb[J * XPU];
+    // DEPTH load stages stay in flight per wave (a tile's K slice is short: the kernel is bound by how many bytes a CU
+    // keeps outstanding, not by MFMA issue): ~28 KiB-chunks of operands per wave, within the register budget
+    constexpr int DEPTH = (28 / (I + J * XPU)) < 2 ? 2 : ((28 / (I + J * XPU)) > 6 ? 6 : (28 / (I + J * XPU)));
+    u32x4 wr[DEPTH][I], xr[DEPTH][J * XPU];
     auto load = [&](u32x4 (&w)[I], u32x4 (&x)[J * XPU], int ku) {
 #pragma unroll
         for (int i = 0; i < I; ++i) {
@@ -126,12 +129,17 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
             }
         }
     };
-    if (ku_lo < ku_hi) load(wa, xa, ku_lo);
-    for (int ku = ku_lo; ku < ku_hi; ku += 2) {
-        if (ku + 1 < ku_hi) load(wb, xb, ku + 1);
-        compute(wa, xa);
-        if (ku + 2 < ku_hi) load(wa, xa, ku + 2);
-        if (ku + 1 < ku_hi) compute(wb, xb);
+    const int nkw = ku_hi - ku_lo;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) if (d < nkw) load(wr[d], xr[d], ku_lo + d);
+    for (int base = 0; base < nkw; base += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (base + d < nkw) {                                     // wave-uniform
+                compute(wr[d], xr[d]);
+                if (base + d + DEPTH < nkw) load(wr[d], xr[d], ku_lo + base + d + DEPTH);
+            }
+        }
     }
     // ---- fold the WAVES K-slices in fixed order through LDS
     f32x4* rv = (f32x4*)red;
@@ -462,18 +470,21 @@ __global__ __launch_bounds__(64) void dec_attn2_combine_kernel(const float* part
 }
 
 // variant = NWAVE*10 + PF  (42 = default: 4 waves, prefetch... see DESIGN.md for the measured choice)
-extern "C" void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, hipStream_t st) {
+// lds_pad: bytes of (unused) dynamic LDS requested per workgroup — an occupancy cap: with two decode chains in flight the
+// attention of one chain must leave registers and wave slots on every CU for the other chain's GEMM workgroups
+extern "C" void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, int lds_pad, hipStream_t st) {
     const dim3 g(p->H, b, p->nsplit);
+    const size_t sh = (size_t)(lds_pad > 0 ? lds_pad : 0);
     switch (variant) {
-        case 20: hipLaunchKernelGGL((dec_attn2_kernel<2, 0>), g, dim3(128), 0, st, *p); break;
-        case 21: hipLaunchKernelGGL((dec_attn2_kernel<2, 1>), g, dim3(128), 0, st, *p); break;
-        case 40: hipLaunchKernelGGL((dec_attn2_kernel<4, 0>), g, dim3(256), 0, st, *p); break;
-        default: hipLaunchKernelGGL((dec_attn2_kernel<4, 1>), g, dim3(256), 0, st, *p); break;
+        case 20: hipLaunchKernelGGL((dec_attn2_kernel<2, 0>), g, dim3(128), sh, st, *p); break;
+        case 21: hipLaunchKernelGGL((dec_attn2_kernel<2, 1>), g, dim3(128), sh, st, *p); break;
+        case 40: hipLaunchKernelGGL((dec_attn2_kernel<4, 0>), g, dim3(256), sh, st, *p); break;
+        default: hipLaunchKernelGGL((dec_attn2_kernel<4, 1>), g, dim3(256), sh, st, *p); break;
     }
     if (p->nsplit > 1 && p->out)
         hipLaunchKernelGGL(dec_attn2_combine_kernel, dim3(p->H, b), dim3(64), 0, st, p->part, p->out, p->H, p->nsplit, p->dim, p->out_packed);
 }
-extern "C" void car_launch_dec_attn2(const Attn2P* p, int b, hipStream_t st) { car_launch_dec_attn2_var(p, b, 41, st); }
+extern "C" void car_launch_dec_attn2(const Attn2P* p, int b, hipStream_t st) { car_launch_dec_attn2_var(p, b, 40, 0, st); }
 // =============================================================================================== prefill -> packed cache
 // k/v of the T prefix rows -> packed cache, RoPE on q,k in place (reference: gpt_t2i.py:266-277).  Same arithmetic as
 // decode.hip prefill_rope_kv_kernel; only the cache addressing differs.

@@ -29,7 +29,9 @@ struct SampleP {
     const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
     int logits_ks; long logits_stride; int round_bf16;
     int stochastic; float temperature; int top_k; float top_p; unsigned long long seed; int row0;
+    const struct SampleDyn* dyn;
 };
+struct SampleDyn { unsigned long long seed; float temperature; int top_k; float top_p; int pad; };
 struct AttnP {
     const void* qkv; void* kcache; void* vcache; const float* rope; const int* pos; const unsigned char* emb_mask;
     void* out; float* part; int H, S_max, T, dim, nsplit;
@@ -54,7 +56,7 @@ struct Norm2P {
 extern "C" {
 int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st);
 int car_pick_gemm_cfg(int M, int N, int K, int epi);
-void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, hipStream_t st);
+void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, int lds_pad, hipStream_t st);
 void car_launch_mask_first_valid(const unsigned char* mask, int* jmin, int b, int T, hipStream_t st);
 void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, hipStream_t st);
 void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st);
@@ -128,6 +130,8 @@ struct car_ctx {
     DevBuf maskb;        // [b, T] uint8
     std::vector<int> h_rowimg;          // host staging that must outlive the async copies of a generate call
     int h_init[16] = {};
+    SampleDyn h_dyn = {};
+    int dbg_skip = 0;
     DevBuf rowimg;       // [b] int: image index of each row
     int st_b = 0, st_T = 0, st_nsteps = 0, st_has_mask = 0; double st_wbytes = 0; const int* st_jmin = nullptr;   // inputs of the lazy decode_algo_bytes
     // decode graph
@@ -739,7 +743,7 @@ struct StepBufs { void *h, *xn, *qkv, *att, *mid, *mid2; float* part; float* log
 // captured step has parallel branches: one chain's HBM-bound attention overlaps the other chains' latency-bound GEMMs
 // (each chain re-streams the weights; a layer's 40 MB sits in the 256 MiB MALL between chains).
 struct FastBufs { bf16_t *xn, *att, *mid, *q; float* logits; float* attn_part; };     // per-chain scratch (XP-packed activations)
-struct Grp { int b0, bg, nsplit; int *pos, *step; FastBufs fb; SampleP sp; };
+struct Grp { int b0, bg, nsplit, attn_variant, attn_lds_pad; int *pos, *step; FastBufs fb; SampleP sp; };
 
 // bf16 fast path (decode2.hip): 7 kernels per layer — norm -> wqkv(+RoPE, KV write) -> attention -> wo(+residual) ->
 // norm -> w1|w3(+SwiGLU) -> w2(+residual); every linear streams the weights once for all rows of the chain.
@@ -783,7 +787,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             Attn2P ap; memset(&ap, 0, sizeof(ap));
             ap.q = fb.q; ap.kc = kc; ap.vc = vc; ap.pos = gr.pos; ap.mask = maskb ? maskb + (size_t)b0 * T : nullptr; ap.jmin = jmin ? jmin + b0 : nullptr;
             ap.out = fb.att; ap.part = fb.attn_part; ap.H = Hn; ap.SA = SA; ap.T = T; ap.dim = D; ap.nsplit = nsplit; ap.out_packed = 1;
-            car_launch_dec_attn2_var(&ap, b, (nsplit == 1 && b < 128) ? 20 : 40, st); nk += nsplit > 1 ? 2 : 1;
+            car_launch_dec_attn2_var(&ap, b, gr.attn_variant, gr.attn_lds_pad, st); nk += nsplit > 1 ? 2 : 1;
         }
         { GemmDP q = z; q.h = h; gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
         {
@@ -937,7 +941,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     { const int wg = b * Hn; while (wg * nsplit < 1024 && nsplit < 16) nsplit *= 2; }
     NEED(c, c->ws[10], (size_t)b * Hn * nsplit * 66 * 4);                     // split-KV partials
     NEED(c, c->ws[11], (size_t)B * (use_control ? n_tok : 1) * D * e);        // condition_mlp output / mlp mid
-    NEED(c, c->scal, (size_t)(16 + 2 * b) * 4);
+    NEED(c, c->scal, (size_t)(16 + 2 * b + 2) * 4 + sizeof(SampleDyn) + 16);
     NEED(c, c->rowimg, (size_t)b * 4);
     NEED(c, c->tok_out, (size_t)B * n_new * 4);
     NEED(c, c->maskb, (size_t)b * T);
@@ -955,9 +959,16 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     HIPCHK(c, hipMemcpyAsync(c->rowimg.p, c->h_rowimg.data(), (size_t)b * 4, hipMemcpyHostToDevice, st));
     car_launch_build_mask(emb_mask, (const int*)c->rowimg.p, (unsigned char*)c->maskb.p, b, T, st);
     int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 16; int* jmin = cur + b;
+    SampleDyn* dyn = (SampleDyn*)(((uintptr_t)(jmin + b) + 15) & ~(uintptr_t)15);
+    c->h_dyn.seed = sp->seed; c->h_dyn.temperature = sp->temperature; c->h_dyn.top_k = sp->top_k; c->h_dyn.top_p = sp->top_p;
+    HIPCHK(c, hipMemcpyAsync(dyn, &c->h_dyn, sizeof(SampleDyn), hipMemcpyHostToDevice, st));
     if (emb_mask) car_launch_mask_first_valid((const unsigned char*)c->maskb.p, jmin, b, T, st);
     {
-        for (int i = 0; i < 8; ++i) { c->h_init[2 * i] = T; c->h_init[2 * i + 1] = 0; }    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
+        // profiling aid (tools/pmc_workload.py): start the decode loop `skip` positions late so that a handful of steps under
+        // counter collection see a long KV prefix.  The skipped cache rows hold zeros / stale rows: tokens are meaningless.
+        int skip = 0; { const char* ev = getenv("CAR_DEBUG_SKIP_STEPS"); if (ev) { skip = atoi(ev); if (skip < 0 || skip > n_new - 2) skip = 0; } }
+        c->dbg_skip = skip;
+        for (int i = 0; i < 8; ++i) { c->h_init[2 * i] = T + skip; c->h_init[2 * i + 1] = skip; }    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
         HIPCHK(c, hipMemcpyAsync(pos, c->h_init, 64, hipMemcpyHostToDevice, st));
     }
 
@@ -1046,6 +1057,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     spp.logits = logits; spp.B = B; spp.V = V; spp.use_cfg = use_cfg; spp.cfg_scale = sp->cfg_scale; spp.cfg_interval = sp->cfg_interval;
     spp.step_ptr = step; spp.n_new = n_new; spp.out_tokens = (int*)c->tok_out.p; spp.cur_tok = cur; spp.forced = forced_tokens; spp.logits_out = logits_out;
     spp.stochastic = sp->sample_logits != 0; spp.temperature = sp->temperature; spp.top_k = sp->top_k; spp.top_p = sp->top_p; spp.seed = sp->seed; spp.row0 = 0;
+    spp.dyn = dyn;     // the sampling scalars live in device memory: changing the seed per call does not invalidate the captured graph
     auto group_sampler = [&](int gi) {      // the sampler of group gi: its rows are [cond ng | uncond ng] starting at row mult*img0[gi]
         SampleP q = spp; const int i0 = img0[gi], ng = img0[gi + 1] - i0; const size_t rb = (size_t)mult * i0;
         q.B = ng; q.row0 = i0; q.logits = logits + rb * V; q.out_tokens = (int*)c->tok_out.p + (size_t)i0 * n_new; q.cur_tok = cur + rb;
@@ -1060,7 +1072,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     StepBufs sb;
     sb.h = h; sb.xn = xn; sb.qkv = qkv; sb.att = att; sb.mid = mid; sb.mid2 = off(mid, (size_t)b * Fh, e);
     sb.part = (float*)c->ws[10].p; sb.logits = logits; sb.pos = pos; sb.step = step; sb.cur = cur;
-    const int nsteps = n_new - 1;
+    const int nsteps = n_new - 1 - c->dbg_skip;
     c->stats.graph_used = 0;
     Grp grp[8]; memset(grp, 0, sizeof(grp));
     if (fast) {
@@ -1072,6 +1084,9 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             gr.b0 = mult * img0[gi]; gr.bg = mult * (img0[gi + 1] - img0[gi]);
             const int bg = gr.bg; const size_t M16 = rup((size_t)bg, 16);
             gr.nsplit = 1; { const int wg = bg * Hn; while (wg * gr.nsplit < 1024 && gr.nsplit < 16) gr.nsplit *= 2; }
+            // attention variant (decode2.hip; profiles/r02_kbench_*): 4 waves per (sequence, head) from 128 sequences up, 2 below
+            gr.attn_variant = (gr.nsplit == 1 && bg < 128) ? 20 : 40; gr.attn_lds_pad = 0;
+            { const char* ev = getenv("CAR_ATTN_VARIANT"); if (ev) gr.attn_variant = atoi(ev); ev = getenv("CAR_ATTN_LDS_PAD"); if (ev) gr.attn_lds_pad = atoi(ev); }
             sizes[gi][0] = M16 * D * 2; sizes[gi][1] = M16 * D * 2; sizes[gi][2] = M16 * Fh * 2; sizes[gi][3] = rup((size_t)bg * D * 2, 16);
             sizes[gi][4] = (size_t)bg * V * 4; sizes[gi][5] = rup((size_t)bg * Hn * gr.nsplit * 66 * 4, 16);
             for (int k = 0; k < 6; ++k) tot += sizes[gi][k];
@@ -1111,8 +1126,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%d|%d|%p|%p", b, B, S_max, n_new, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
                  (const void*)forced_tokens, (void*)logits_out);
-        { char kb2[200]; snprintf(kb2, sizeof(kb2), "|%d|%g|%d|%g|%llu|gen%llu|%p|%p|%p|%p", sp->sample_logits, (double)sp->temperature, sp->top_k, (double)sp->top_p,
-                                   (unsigned long long)sp->seed, g_alloc_gen, xn, att, mid, c->scal.p); strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
+        { char kb2[200]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad);
+          strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
         bool graph_ok = true;
         if (getenv("CAR_NO_GRAPH")) { /* skip capture */ }
@@ -1190,7 +1205,7 @@ extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
         if (c->st_has_mask && c->st_jmin && c->st_b > 0) { (void)hipStreamSynchronize(c->stream); if (hipMemcpy(jm.data(), c->st_jmin, (size_t)c->st_b * 4, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError(); }
         double kvb = 0;
         for (int s = 0; s < c->st_b; ++s)
-            for (int i = 0; i < c->st_nsteps; ++i) { const double p = c->st_T + i; kvb += 2.0 * g.n_layer * g.dim * (double)c->esz * (p + 1 - jm[(size_t)s]); }
+            for (int i = 0; i < c->st_nsteps; ++i) { const double p = c->st_T + c->dbg_skip + i; kvb += 2.0 * g.n_layer * g.dim * (double)c->esz * (p + 1 - jm[(size_t)s]); }
         c->stats.decode_algo_bytes = (int64_t)(c->st_wbytes * c->st_nsteps + kvb);
     }
     *out = c->stats;

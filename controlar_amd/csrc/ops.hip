@@ -538,7 +538,9 @@ struct SampleP {
     const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
     int logits_ks; long logits_stride; int round_bf16;   // logits given as split-K partials [ks][b][V]; bf16 rounding of the sum (gpt_t2i.py:470)
     int stochastic; float temperature; int top_k; float top_p; unsigned long long seed; int row0;   // sample_logits=True path (generate.py:59-74)
+    const struct SampleDyn* dyn;    // when set, (seed, temperature, top_k, top_p) are read from device memory: a captured graph stays valid across calls
 };
+struct SampleDyn { unsigned long long seed; float temperature; int top_k; float top_p; int pad; };
 // 4 consecutive logits of `row` starting at column j (V % 4 == 0)
 __device__ inline void sample_logit4(const SampleP& p, long row, int j, float (&v)[4]) {
     if (p.logits_ks <= 0) { const float4 u = *(const float4*)(p.logits + row * p.V + j); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; return; }
@@ -616,6 +618,7 @@ __global__ __launch_bounds__(1024) void sample_stochastic_kernel(SampleP p, int 
     extern __shared__ float keys[];          // Vp floats (Vp = pow2 >= V), sorted descending
     __shared__ float sm[40]; __shared__ int cut_s; __shared__ int tok_s;
     const int i = blockIdx.x, step = *p.step_ptr, tid = threadIdx.x, nt = blockDim.x;
+    if (p.dyn) { p.seed = p.dyn->seed; p.temperature = p.dyn->temperature; p.top_k = p.dyn->top_k; p.top_p = p.dyn->top_p; }
     const bool mix = p.use_cfg && !(p.cfg_interval > -1 && (step - 1) > p.cfg_interval);
     const float invT = 1.0f / fmaxf(p.temperature, 1e-5f);
     float* lo = p.logits_out ? p.logits_out + ((long)i * p.n_new + step) * p.V : nullptr;
@@ -682,22 +685,31 @@ __global__ __launch_bounds__(1024) void sample_stochastic_kernel(SampleP p, int 
     }
     float total; const float excl = block_excl_scan(loc, sm, total);
     const float target = philox_uniform(p.seed, (unsigned)(p.row0 + i), (unsigned)step) * total;
+    // owner of the draw = the LAST thread with a non-empty chunk whose exclusive prefix is <= target.  (Testing
+    // excl <= target < excl + loc per thread can select nobody: the scan's excl(t+1) is not bit-equal to excl(t) + loc(t).)
+    // The first non-empty chunk has excl == 0 exactly, so an owner always exists and the token is always in the support.
     if (tid == 0) tok_s = -1;
     __syncthreads();
-    if (target >= excl && (target < excl + loc || tid == nt - 1)) {
+    if (loc > 0.f && excl <= target) atomicMax(&tok_s, tid);
+    __syncthreads();
+    const int owner = tok_s;
+    __syncthreads();
+    if (tid == 0) tok_s = -1;
+    __syncthreads();
+    if (tid == owner) {
         float run = excl; int pick = -1, last = -1;
         for (int j = j0; j < j0 + per && j < p.V; j += 4) {
             float v[4]; mixed4(j, v);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float x = v[e] * invT; if (x >= thr) { run += expf(x - mx); last = j + e; if (pick < 0 && run > target) pick = j + e; } }
         }
-        if (pick < 0) pick = last;
-        if (pick >= 0) atomicMax(&tok_s, pick);
+        if (pick < 0) pick = last;                // rounding left the running sum at or below target: the chunk's last kept token
+        tok_s = pick;
     }
     __syncthreads();
     if (tid == 0) {
         int t = tok_s;
-        if (t < 0) { t = 0; }       // numerically impossible unless all logits are -inf
+        if (t < 0) { t = 0; }       // only if every logit is -inf / NaN (no support at all)
         p.out_tokens[(long)i * p.n_new + step] = t;
         const int fb = p.forced ? p.forced[(long)i * p.n_new + step] : t;
         p.cur_tok[i] = fb;

@@ -8,11 +8,20 @@ import torch
 from .models import Transformer, _PendingControl
 
 
+def _call_seed(kw) -> int:
+    """Seed of the library's counter-based RNG for this call.  The reference draws from torch's global generator
+    (torch.multinomial, generate.py:72), so consecutive calls differ and torch.manual_seed() reproduces a run; the same holds
+    here: without an explicit `seed` kwarg (an extension) one 62-bit value is drawn from torch's CPU generator per call."""
+    if "seed" in kw and kw["seed"] is not None:
+        return int(kw["seed"])
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
 @torch.no_grad()
 def generate(model: Transformer, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, condition=None,
              condition_null=None, condition_token_nums=0, control_strength=1, **sampling_kwargs):
-    """Returns int32 [B, max_new_tokens] on cond.device.  sampling_kwargs: temperature, top_k, top_p, sample_logits
-    (generate.py:59).  `condition` is the control image [B,3,H,W] in [-1,1] (or None)."""
+    """Returns int32 [B, max_new_tokens] on cond.device.  sampling_kwargs: temperature, top_k (default 2000 as sample(),
+    generate.py:59), top_p, sample_logits (default True).  `condition` is the control image [B,3,H,W] in [-1,1] (or None)."""
     if model.model_type not in ("t2i", "c2i"):
         raise Exception("please check model type")
     eng = model.engine
@@ -27,7 +36,7 @@ def generate(model: Transformer, cond, max_new_tokens, emb_masks=None, cfg_scale
         raise RuntimeError("c2i: condition_token_nums must be 0 (the only value the reference samplers pass, sample_c2i.py:55)")
     out = eng.generate(cond, int(max_new_tokens), emb_masks, cfg_scale=float(cfg_scale), cfg_interval=int(cfg_interval),
                        use_control=condition is not None, control_strength=float(control_strength),
-                       temperature=float(sampling_kwargs.get("temperature", 1.0)), top_k=int(sampling_kwargs.get("top_k", 0) or 0),
+                       temperature=float(sampling_kwargs.get("temperature", 1.0)), top_k=int(sampling_kwargs.get("top_k", 2000) or 0),
                        top_p=float(sampling_kwargs.get("top_p", 1.0)), sample_logits=bool(sampling_kwargs.get("sample_logits", True)),
-                       seed=int(sampling_kwargs.get("seed", 0)))
+                       seed=_call_seed(sampling_kwargs))
     return out.to(cond.device)

@@ -176,7 +176,7 @@ static void test_qkv_attn(const AttnCase& c) {
     a.H = H; a.SA = SA; a.T = T; a.dim = dim; a.nsplit = c.nsplit; a.out_packed = c.packed_out;
     int* dJ = dalloc<int>(b);
     if (c.maskmode && (c.variant % 2 == 0 || c.variant == 41)) { car_launch_mask_first_valid(dM, dJ, b, T, 0); a.jmin = dJ; }     // both jmin sources get exercised
-    car_launch_dec_attn2_var(&a, b, c.variant, 0);
+    car_launch_dec_attn2_var(&a, b, c.variant, 0, 0);
     CK(hipDeviceSynchronize());
     // cache rows written by the epilogue
     auto kc2 = d2h(dK, kc.size()), vc2 = d2h(dV, vc.size()); auto q2 = d2h(dQ, (size_t)b * dim);
@@ -323,7 +323,7 @@ static void bench_attn(bool quick) {
         for (int variant : {41, 40, 21, 20, 141}) {
             Attn2P a; memset(&a, 0, sizeof(a)); a.q = dQ; a.pos = dPos; a.mask = dM; a.out = dO; a.part = dPart; a.H = H; a.SA = SA; a.T = T; a.dim = dim; a.nsplit = c.nsplit; a.out_packed = 1;
             a.jmin = variant == 141 ? nullptr : dJ;             // 141: variant 41 with the in-kernel mask scan
-            const float us = time_launches(quick ? 30 : 60, [&](int it) { Attn2P q = a; q.kc = dKV + per * 2 * (it % NLAY); q.vc = q.kc + per; car_launch_dec_attn2_var(&q, c.b, variant % 100, 0); });
+            const float us = time_launches(quick ? 30 : 60, [&](int it) { Attn2P q = a; q.kc = dKV + per * 2 * (it % NLAY); q.vc = q.kc + per; car_launch_dec_attn2_var(&q, c.b, variant % 100, 0, 0); });
             printf("  v%d: %.1f us %.2f TB/s", variant, us, bytes / 1e6 / us);
         }
         printf("\n"); fflush(stdout);
@@ -345,6 +345,7 @@ int main(int argc, char** argv) {
     for (int variant : {41, 40, 21, 20}) for (auto c : cases) { c.variant = variant; test_qkv_attn(c); }
     printf("== correctness: %d failure(s)\n", g_fail);
     fflush(stdout);
-    if (!noperf) { bench_attn(quick); bench_gemm(quick); }
+    const bool only_gemm = argc > 1 && !strcmp(argv[1], "gemm");
+    if (!noperf) { if (!only_gemm) bench_attn(quick); bench_gemm(quick); }
     return g_fail ? 1 : 0;
 }

@@ -1,14 +1,17 @@
 """Minimal workload for rocprofv3 --pmc passes (counter collection serialises and slows every dispatch):
-XL weights, B sequences, encode + prefill + a few decode steps at a late position (long KV) — eager launches, one chain."""
+XL weights, B sequences, encode + prefill + a few eager decode steps.  CAR_DEBUG_SKIP_STEPS=<n> starts the loop n positions
+late (engine.hip) so that the few profiled steps run over a long KV prefix.
+usage: pmc_workload.py B n_new [skip]   -> decode steps profiled = n_new - 1 - skip at positions 120+skip .."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("CAR_NO_GRAPH", "1")
-pass  # chains stay as in production (eager launches run them back to back on one stream)
+os.environ.setdefault("CAR_NO_GRAPH", "1")      # PMC collection cannot follow graph replays: eager launches, chains back to back
 import torch
 from controlar_amd import config as C, synth
 from controlar_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n_new = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+if len(sys.argv) > 3:
+    os.environ["CAR_DEBUG_SKIP_STEPS"] = sys.argv[3]
 cfg = C.xl_t2i(1024)
 gsd, _ = synth.path_state_dicts(cfg, 0)
 eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
