@@ -55,6 +55,8 @@ SYMBOLS = {
     "car_abi_version": (C.c_int, []),
     "car_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "car_finalize_weights": (C.c_int, [C.c_void_p]),
+    "car_export_packed": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "car_import_packed": (C.c_int, [C.c_void_p, C.c_char_p]),
     "car_encode_control": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "car_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                C.POINTER(CarSampling), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

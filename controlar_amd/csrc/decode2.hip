@@ -523,17 +523,21 @@ struct Norm2P {
     const bf16_t* ctrl; const int* pos; int add; int T; int n_tok; float cs;
     int D; float eps;
 };
-__global__ __launch_bounds__(1024) void rmsnorm2_kernel(Norm2P p) {
-    __shared__ float sm[20];
-    const long r = blockIdx.x;
+// one WAVE per row (4 rows per workgroup): a decode-step row is 2.5 KB, so the kernel is pure latency — no LDS, no barrier,
+// the sum of squares folds through wave shuffles in a fixed order.  Lane l owns column groups l, l+64, ... (4 columns each).
+template <int NQ>
+__global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
     const int D = p.D, ng = D >> 2;
     const bf16_t* src = p.idx ? p.emb + (long)p.idx[r] * D : p.h_in + r * D;
     const bf16_t* add = p.add ? p.ctrl + (r * p.n_tok + (*p.pos - p.T + 1)) * D : nullptr;
-    float val[4][4];
+    float val[NQ][4];
     float ss = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int gi = threadIdx.x + q * blockDim.x;
+    for (int q = 0; q < NQ; ++q) {
+        const int gi = lane + q * 64;
         if (gi < ng) {
             const uint2 u = *(const uint2*)(src + gi * 4);
             float v[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
@@ -547,11 +551,11 @@ __global__ __launch_bounds__(1024) void rmsnorm2_kernel(Norm2P p) {
             for (int e = 0; e < 4; ++e) { val[q][e] = v[e]; ss += v[e] * v[e]; }
         }
     }
-    const float rstd = rsqrtf(block_sum(ss, sm) / D + p.eps);
+    const float rstd = rsqrtf(wave_sum(ss) / D + p.eps);
     const int nkb = D >> 5;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int gi = threadIdx.x + q * blockDim.x;
+    for (int q = 0; q < NQ; ++q) {
+        const int gi = lane + q * 64;
         if (gi < ng) {
             const int k = gi * 4;
             if (p.h_out) { uint2 u; u.x = pack_bf16x2(val[q][0], val[q][1]); u.y = pack_bf16x2(val[q][2], val[q][3]); *(uint2*)(p.h_out + r * D + k) = u; }
@@ -567,6 +571,9 @@ __global__ __launch_bounds__(1024) void rmsnorm2_kernel(Norm2P p) {
     }
 }
 extern "C" void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st) {
-    int ng = p->D / 4, th = ((ng + 63) / 64) * 64; if (th > 1024) th = 1024; if (th < 64) th = 64;
-    hipLaunchKernelGGL(rmsnorm2_kernel, dim3(rows), dim3(th), 0, st, *p);
+    const int nq = (p->D / 4 + 63) / 64;                      // column groups per lane (D <= 4096: every LlamaGen size)
+    const dim3 g((unsigned)((rows + 3) / 4)), b(256);
+    if (nq <= 4) hipLaunchKernelGGL((rmsnorm2_kernel<4>), g, b, 0, st, *p, (int)rows);
+    else if (nq <= 8) hipLaunchKernelGGL((rmsnorm2_kernel<8>), g, b, 0, st, *p, (int)rows);
+    else hipLaunchKernelGGL((rmsnorm2_kernel<16>), g, b, 0, st, *p, (int)rows);
 }

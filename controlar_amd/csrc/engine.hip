@@ -61,6 +61,11 @@ void car_launch_mask_first_valid(const unsigned char* mask, int* jmin, int b, in
 void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, hipStream_t st);
 void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st);
 void car_launch_build_mask(const int64_t* emb_mask, const int* row_img, unsigned char* out, int b, int T, hipStream_t st);
+// pack.hip
+void car_launch_rows_to_bf16(const void* src, int dtype, void* dst, long N, long K, int ileave, hipStream_t st);
+void car_launch_pack_frag_bf16(const void* src, void* dst, long N, long K, hipStream_t st);
+void car_launch_row_amax_scale(const void* src, int dtype, float* scale, long N, long K, int ileave, hipStream_t st);
+void car_launch_quant_pack_fp8(const void* src, int dtype, const float* scale, void* rowmajor, void* pk, long N, long K, int ileave, hipStream_t st);
 void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
 void car_launch_convert(int mode, const void* src, int src_dtype, void* dst, long n, hipStream_t st);
 void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg, hipStream_t st);
@@ -103,7 +108,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct Wt { void* p = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
+struct Wt { void* p = nullptr; std::vector<int64_t> shape; int64_t numel = 0; size_t bytes = 0; };
 
 struct car_ctx {
     car_config cfg; int mode = 0; size_t esz = 4;
@@ -111,7 +116,8 @@ struct car_ctx {
     hipStream_t streamx[7] = {}; hipEvent_t ev_fork = nullptr, ev_joinx[7] = {};
     hipStream_t stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
     std::unordered_map<std::string, Wt> w;            // packed weights by (reference) name, element type T unless noted
-    std::unordered_map<std::string, std::vector<float>> host_keep;   // host fp32 copies needed later (pos-emb, w1/w3 halves)
+    std::unordered_map<std::string, std::vector<float>> host_keep;   // host fp32 copies needed later (pos-emb, w1/w3 halves in exact mode)
+    std::unordered_map<std::string, int> w13_seen;                    // fast mode: bit 0 = w1 arrived, bit 1 = w3 arrived (per layer prefix)
     bool finalized = false, has_gpt = false;
     // cached tables
     std::map<std::pair<int, int>, void*> pos_cache;   // (gh,gw) -> T [1+gh*gw, D]
@@ -237,6 +243,7 @@ static int upload(car_ctx* c, const std::string& name, const std::vector<float>&
     Wt t; t.shape = shape; t.numel = (int64_t)h.size();
     const bool f32 = force_f32 || c->mode == CAR_F32;
     const size_t bytes = h.size() * (f32 ? 4 : 2);
+    t.bytes = bytes;
     HIPCHK(c, hipMalloc(&t.p, bytes ? bytes : 4));
     if (f32) { HIPCHK(c, hipMemcpy(t.p, h.data(), bytes, hipMemcpyHostToDevice)); }
     else {
@@ -278,32 +285,6 @@ extern "C" int car_debug_f32_to_e4m3(const float* in, unsigned char* out, int64_
     return 0;
 }
 
-// fp8 decode weights: per-row scale s_n = amax_n / 448; image [N/16][K/64][64 lanes][16 B] (lane l: row l&15, 8 bytes of
-// k-block 2j then 8 bytes of k-block 2j+1, k offset (l>>4)*8).  `h` is overwritten with the DEQUANTISED values so that the
-// row-major copy used by prefill sees the same effective weights.
-static int upload_packed_fp8(car_ctx* c, const std::string& name, std::vector<float>& h, int N, int K) {
-    if (N % 16 || K % 64) FAIL(c, "%s: fp8 decode packing needs N%%16==0 and K%%64==0 (got %d x %d)", name.c_str(), N, K);
-    std::vector<float> sc((size_t)N);
-    std::vector<unsigned char> q((size_t)N * K);
-    for (int n = 0; n < N; ++n) {
-        float amax = 0.f; for (int k = 0; k < K; ++k) amax = std::fmax(amax, std::fabs(h[(size_t)n * K + k]));
-        const float s = amax > 0.f ? amax / 448.0f : 1.0f; sc[(size_t)n] = s;
-        for (int k = 0; k < K; ++k) { const unsigned char v = f32_to_e4m3(h[(size_t)n * K + k] / s); q[(size_t)n * K + k] = v; h[(size_t)n * K + k] = e4m3_to_f32(v) * s; }
-    }
-    std::vector<unsigned char> pk((size_t)N * K);
-    const int nkp = K / 64;
-    for (int rb = 0; rb < N / 16; ++rb) for (int kp = 0; kp < nkp; ++kp) for (int l = 0; l < 64; ++l) for (int half = 0; half < 2; ++half) {
-        const unsigned char* src = &q[(size_t)(rb * 16 + (l & 15)) * K + (kp * 2 + half) * 32 + (l >> 4) * 8];
-        memcpy(&pk[((((size_t)rb * nkp + kp) * 64 + l) * 2 + half) * 8], src, 8);
-    }
-    Wt t; t.shape = {N, K}; t.numel = (int64_t)N * K;
-    HIPCHK(c, hipMalloc(&t.p, pk.size()));
-    HIPCHK(c, hipMemcpy(t.p, pk.data(), pk.size(), hipMemcpyHostToDevice));
-    auto it = c->w.find(name + "#pk8"); if (it != c->w.end() && it->second.p) (void)hipFree(it->second.p);
-    c->w[name + "#pk8"] = t;
-    return upload(c, name + "#sc", sc, {N}, true);
-}
-
 // dec_linear weight image: [N/16][K/32] chunks of 64 lanes x 8 bf16 (lane l: row l&15, k (l>>4)*8..+8) — decode.hip
 static void pack_decode_bf16(const float* h, int N, int K, bf16_t* pk) {
     const int nkb = K / 32;
@@ -318,19 +299,50 @@ extern "C" int car_debug_pack_decode_weight(const float* w, int32_t N, int32_t K
     pack_decode_bf16(w, N, K, out);
     return 0;
 }
-static int upload_packed(car_ctx* c, const std::string& name, std::vector<float>& h, int N, int K) {
-    if (c->mode != CAR_BF16) return 0;
-    if (c->cfg.decode_weight_fp8) return upload_packed_fp8(c, name, h, N, K);
-    if (N % 16 || K % 32) FAIL(c, "%s: decode packing needs N%%16==0 and K%%32==0 (got %d x %d)", name.c_str(), N, K);
-    std::vector<bf16_t> pk((size_t)N * K);
-    pack_decode_bf16(h.data(), N, K, pk.data());
-    Wt t; t.shape = {N, K}; t.numel = (int64_t)N * K;
-    HIPCHK(c, hipMalloc(&t.p, pk.size() * 2));
-    HIPCHK(c, hipMemcpy(t.p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
-    auto it = c->w.find(name + "#pk");
+// ---- device-side packing of one decode linear (pack.hip).  `name` is the row-major image ([Ntot, K] bf16, the prefill operand:
+// for w1 / w3 the 16-row interleaved "w13" image); `src` is the checkpoint tensor [Nsrc, K] in `dtype` (host or device).
+// bf16 weights: name#pk = MFMA-fragment image.  fp8 weights: name#pk8 = e4m3 image, name#sc = fp32 row scales, and the
+// row-major image holds the DEQUANTISED values so that prefill and decode see one set of effective weights.
+static int ensure_w(car_ctx* c, const std::string& name, size_t bytes, const std::vector<int64_t>& shape, int64_t numel) {
+    auto it = c->w.find(name);
+    if (it != c->w.end() && it->second.p && it->second.bytes == bytes) return 0;
     if (it != c->w.end() && it->second.p) (void)hipFree(it->second.p);
-    c->w[name + "#pk"] = t;
+    Wt t; t.shape = shape; t.numel = numel; t.bytes = bytes;
+    HIPCHK(c, hipMalloc(&t.p, bytes ? bytes : 4));
+    c->w[name] = t;
     return 0;
+}
+static int dev_linear(car_ctx* c, const std::string& name, const void* src, bool on_dev, int dtype, int Nsrc, int K, int ileave, int Ntot) {
+    const bool f8 = c->cfg.decode_weight_fp8 != 0;
+    if (Ntot % 16 || K % (f8 ? 64 : 32)) FAIL(c, "%s: decode packing needs N%%16==0 and K%%%d==0 (got %d x %d)", name.c_str(), f8 ? 64 : 32, Ntot, K);
+    const size_t eb = dtype == CAR_DT_F32 ? 4 : 2;
+    void* stage = nullptr;
+    if (!on_dev) {
+        HIPCHK(c, hipMalloc(&stage, (size_t)Nsrc * K * eb));
+        HIPCHK(c, hipMemcpy(stage, src, (size_t)Nsrc * K * eb, hipMemcpyHostToDevice));
+        src = stage;
+    }
+    const int dt = dtype == CAR_DT_F32 ? 0 : 1;
+    int rc = ensure_w(c, name, (size_t)Ntot * K * 2, {Ntot, K}, (int64_t)Ntot * K);
+    bool complete = ileave == 0;
+    if (!rc && ileave) { int& seen = c->w13_seen[name]; seen |= ileave; complete = seen == 3; }
+    if (!rc && !f8) {
+        car_launch_rows_to_bf16(src, dt, c->w[name].p, Nsrc, K, ileave, 0);
+        if (complete) {
+            rc = ensure_w(c, name + "#pk", (size_t)Ntot * K * 2, {Ntot, K}, (int64_t)Ntot * K);
+            if (!rc) car_launch_pack_frag_bf16(c->w[name].p, c->w[name + "#pk"].p, Ntot, K, 0);
+        }
+    } else if (!rc) {
+        rc = ensure_w(c, name + "#sc", (size_t)Ntot * 4, {Ntot}, Ntot);
+        if (!rc) rc = ensure_w(c, name + "#pk8", (size_t)Ntot * K, {Ntot, K}, (int64_t)Ntot * K);
+        if (!rc) {
+            car_launch_row_amax_scale(src, dt, (float*)c->w[name + "#sc"].p, Nsrc, K, ileave, 0);
+            car_launch_quant_pack_fp8(src, dt, (const float*)c->w[name + "#sc"].p, c->w[name].p, c->w[name + "#pk8"].p, Nsrc, K, ileave, 0);
+        }
+    }
+    if (!rc) { hipError_t e2 = hipStreamSynchronize(0); if (e2 == hipSuccess) e2 = hipGetLastError(); if (e2 != hipSuccess) { c->err = std::string("device packing failed: ") + hipGetErrorString(e2); rc = -1; } }
+    if (stage) (void)hipFree(stage);
+    return rc;
 }
 
 static void replace_all(std::string& s, const std::string& a, const std::string& b) {
@@ -363,6 +375,26 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
         name == "quantize.codebook_used") return 0;
     std::vector<int64_t> shp(shape, shape + ndim);
     int64_t n = 1; for (auto s : shp) n *= s;
+    {
+        // fast mode: the five decode linears are packed on the device straight from the checkpoint tensor (pack.hip)
+        const car_config& g0 = c->cfg;
+        const bool is13 = ends_with(name, "feed_forward.w1.weight") || ends_with(name, "feed_forward.w3.weight");
+        const bool islin = ndim == 2 && (ends_with(name, "attention.wqkv.weight") || ends_with(name, "attention.wo.weight") ||
+                                         ends_with(name, "feed_forward.w2.weight") || name == "output.weight");
+        if (c->mode == CAR_BF16 && (is13 || islin)) {
+            hipPointerAttribute_t at; bool on_dev = false;
+            if (hipPointerGetAttributes(&at, ptr) == hipSuccess) on_dev = (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged);
+            else (void)hipGetLastError();
+            c->finalized = false;
+            if (is13) {
+                if (ndim != 2 || shp[0] != g0.ffn_hidden || shp[1] != g0.dim) FAIL(c, "%s: expected [%d,%d]", cname, g0.ffn_hidden, g0.dim);
+                const bool is1 = ends_with(name, "w1.weight");
+                const std::string base = name.substr(0, name.size() - strlen("w1.weight"));
+                return dev_linear(c, base + "w13.weight", ptr, on_dev, dtype, g0.ffn_hidden, g0.dim, is1 ? 1 : 2, 2 * g0.ffn_hidden);
+            }
+            return dev_linear(c, name, ptr, on_dev, dtype, (int)shp[0], (int)shp[1], 0, (int)shp[0]);
+        }
+    }
     // bring to host fp32
     std::vector<float> h((size_t)n);
     {
@@ -394,8 +426,7 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
             memcpy(&pk[blk * g.dim], &w1[(size_t)r * g.dim], (size_t)g.dim * 4);
             memcpy(&pk[(blk + 16) * g.dim], &w3[(size_t)r * g.dim], (size_t)g.dim * 4);
         }
-        int rc = upload_packed(c, base + "w13.weight", pk, 2 * g.ffn_hidden, g.dim);     // (fp8: pk becomes the dequantised image)
-        if (!rc) rc = upload(c, base + "w13.weight", pk, {2 * (int64_t)g.ffn_hidden, g.dim});
+        int rc = upload(c, base + "w13.weight", pk, {2 * (int64_t)g.ffn_hidden, g.dim});        // exact mode only (fast mode: dev_linear above)
         c->host_keep.erase(other);
         return rc;
     }
@@ -428,10 +459,6 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
         return upload(c, name, pk, {Co, 9 * (int64_t)Ci});
     }
     if ((starts_with(name, "decoder.") || starts_with(name, "encoder.") || starts_with(name, "quant_conv.")) && ndim == 4) return upload(c, name, h, {shp[0], shp[1]});   // 1x1 conv
-    if (ndim == 2 && (ends_with(name, "attention.wqkv.weight") || ends_with(name, "attention.wo.weight") ||
-                      ends_with(name, "feed_forward.w2.weight") || name == "output.weight")) {
-        if (upload_packed(c, name, h, (int)shp[0], (int)shp[1])) return -1;
-    }
     return upload(c, name, h, shp);
 }
 
@@ -536,9 +563,87 @@ extern "C" int car_finalize_weights(car_ctx* c) {
         }
         for (auto& r : vr) if (!Wp(c, r)) { if (nmiss < 6) missing += r + " "; ++nmiss; }
     }
+    if (!vq_only && c->mode == CAR_BF16) {       // fast mode: every decode linear must have its packed image (both w1 and w3 arrived)
+        const char* sfx = g.decode_weight_fp8 ? "#pk8" : "#pk";
+        std::vector<std::string> lin = {"output.weight"};
+        for (int i = 0; i < g.n_layer; ++i) {
+            const std::string p = "layers." + std::to_string(i) + ".";
+            for (const char* s : {"attention.wqkv.weight", "attention.wo.weight", "feed_forward.w13.weight", "feed_forward.w2.weight"}) lin.push_back(p + s);
+            auto it = c->w13_seen.find(p + "feed_forward.w13.weight");
+            if (it != c->w13_seen.end() && it->second != 3) { if (nmiss < 6) missing += p + (it->second == 1 ? "feed_forward.w3.weight " : "feed_forward.w1.weight "); ++nmiss; }
+        }
+        for (auto& r : lin) if (Wp(c, r) && !Wp(c, r + sfx)) { if (nmiss < 6) missing += r + sfx + " "; ++nmiss; }
+    }
     if (nmiss) FAIL(c, "car_finalize_weights: %d required tensors missing, e.g. %s", nmiss, missing.c_str());
     c->finalized = true;
     return 0;
+}
+
+// ------------------------------------------------------------------------------------- packed-image cache
+// The reference re-reads and re-loads its checkpoints on every start (sample_t2i.py:64-83; demo/model.py:66-75 even per request).
+// car_export_packed writes every device-resident weight image of a finalised context (row-major operands, MFMA-fragment / e4m3
+// images, scales, conv layouts) plus the host-side tables into one file; car_import_packed restores them with plain copies —
+// no conversion, no packing — into a context created with the SAME car_config.  Layout: magic, car_config, entry count, then
+// per entry {kind, name, shape, numel, bytes, payload}.  The caller keys the file (controlar_amd/checkpoint.py: content hash).
+static const char kPackMagic[8] = {'C', 'A', 'R', 'P', 'K', '0', '2', 0};
+static bool same_config(const car_config& a, const car_config& b) {
+    car_config x = a, y = b; x.stream_priority = y.stream_priority = 0;
+    return memcmp(&x, &y, sizeof(car_config)) == 0;
+}
+extern "C" int car_export_packed(car_ctx* c, const char* path) {
+    if (!c || !path) return -1;
+    if (!c->finalized) FAIL(c, "car_export_packed: call car_finalize_weights first");
+    (void)hipDeviceSynchronize();
+    FILE* f = fopen(path, "wb");
+    if (!f) FAIL(c, "car_export_packed: cannot open %s for writing", path);
+    bool ok = fwrite(kPackMagic, 1, 8, f) == 8 && fwrite(&c->cfg, sizeof(car_config), 1, f) == 1;
+    const uint64_t n = c->w.size() + c->host_keep.size();
+    ok = ok && fwrite(&n, 8, 1, f) == 1;
+    std::vector<unsigned char> buf;
+    auto put = [&](uint32_t kind, const std::string& name, const std::vector<int64_t>& shape, int64_t numel, const void* data, uint64_t bytes) {
+        const uint32_t nl = (uint32_t)name.size(), nd = (uint32_t)shape.size();
+        ok = ok && fwrite(&kind, 4, 1, f) == 1 && fwrite(&nl, 4, 1, f) == 1 && fwrite(name.data(), 1, nl, f) == nl && fwrite(&nd, 4, 1, f) == 1;
+        if (nd) ok = ok && fwrite(shape.data(), 8, nd, f) == nd;
+        ok = ok && fwrite(&numel, 8, 1, f) == 1 && fwrite(&bytes, 8, 1, f) == 1;
+        if (bytes) ok = ok && fwrite(data, 1, bytes, f) == bytes;
+    };
+    for (auto& kv : c->w) {
+        const Wt& t = kv.second;
+        buf.resize(t.bytes);
+        if (t.bytes && hipMemcpy(buf.data(), t.p, t.bytes, hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); FAIL(c, "car_export_packed: device read of %s failed", kv.first.c_str()); }
+        put(0, kv.first, t.shape, t.numel, buf.data(), t.bytes);
+    }
+    for (auto& kv : c->host_keep) put(1, kv.first, {(int64_t)kv.second.size()}, (int64_t)kv.second.size(), kv.second.data(), kv.second.size() * 4);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { remove(path); FAIL(c, "car_export_packed: short write to %s", path); }
+    return 0;
+}
+extern "C" int car_import_packed(car_ctx* c, const char* path) {
+    if (!c || !path) return -1;
+    FILE* f = fopen(path, "rb");
+    if (!f) FAIL(c, "car_import_packed: cannot open %s", path);
+    char magic[8]; car_config cfg; uint64_t n = 0;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kPackMagic, 8) || fread(&cfg, sizeof(car_config), 1, f) != 1 || fread(&n, 8, 1, f) != 1) { fclose(f); FAIL(c, "car_import_packed: %s is not a packed-weight file of this library version", path); }
+    if (!same_config(cfg, c->cfg)) { fclose(f); FAIL(c, "car_import_packed: %s was written for a different car_config", path); }
+    std::vector<unsigned char> buf;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t kind = 0, nl = 0, nd = 0; int64_t numel = 0; uint64_t bytes = 0;
+        bool ok = fread(&kind, 4, 1, f) == 1 && fread(&nl, 4, 1, f) == 1 && nl < 4096;
+        std::string name((size_t)nl, ' ');
+        ok = ok && fread(&name[0], 1, nl, f) == nl && fread(&nd, 4, 1, f) == 1 && nd <= 8;
+        std::vector<int64_t> shape(nd);
+        if (ok && nd) ok = fread(shape.data(), 8, nd, f) == nd;
+        ok = ok && fread(&numel, 8, 1, f) == 1 && fread(&bytes, 8, 1, f) == 1;
+        if (ok) { buf.resize(bytes); if (bytes) ok = fread(buf.data(), 1, bytes, f) == bytes; }
+        if (!ok) { fclose(f); FAIL(c, "car_import_packed: %s is truncated", path); }
+        if (kind == 1) { std::vector<float> v((size_t)numel); memcpy(v.data(), buf.data(), bytes); c->host_keep[name] = std::move(v); continue; }
+        if (ensure_w(c, name, bytes, shape, numel)) { fclose(f); return -1; }
+        if (bytes && hipMemcpy(c->w[name].p, buf.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { fclose(f); FAIL(c, "car_import_packed: upload of %s failed", name.c_str()); }
+        if (ends_with(name, "feed_forward.w13.weight")) c->w13_seen[name] = 3;
+    }
+    fclose(f);
+    c->finalized = false;
+    return car_finalize_weights(c);
 }
 
 // ------------------------------------------------------------------------------------- small host-side tables

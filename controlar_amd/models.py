@@ -47,18 +47,37 @@ class Transformer:
         self._device = None
         self._sd: Dict[str, torch.Tensor] = {}
         self._engine: Optional[Engine] = None
+        self._ckpt = None
         self.tok_embeddings = SimpleNamespace(weight=SimpleNamespace(dtype=self._dtype))
         self.cls_embedding = SimpleNamespace(uncond_embedding=None)
         self.max_batch_size = self.max_seq_length = -1
         self.training = False
 
     # ---- torch.nn.Module look-alikes used by the sampler scripts
-    def load_state_dict(self, sd, strict: bool = False):
+    def load_state_dict(self, sd, strict: bool = True):
+        """torch.nn.Module.load_state_dict semantics (the samplers pass strict=False, sample_t2i.py:69,81): returns the real
+        missing / unexpected key lists against the parameters this path reads; strict=True raises on either."""
+        from .checkpoint import IGNORED_GPT, expected_gpt_keys, key_report
+        missing, unexpected = key_report(expected_gpt_keys(self.cfg), list(sd.keys()), IGNORED_GPT)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for Transformer: Missing key(s): {missing[:8]}{'...' if len(missing) > 8 else ''} "
+                               f"Unexpected key(s): {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
         self._sd.update({k: v for k, v in sd.items() if torch.is_tensor(v)})
         if "cls_embedding.uncond_embedding" in sd:
             self.cls_embedding.uncond_embedding = sd["cls_embedding.uncond_embedding"]
         self._engine = None
-        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+        self._ckpt = None
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def load_checkpoint(self, path: str, cache_dir: Optional[str] = None, use_cache: bool = True):
+        """sample_t2i.py:64-83 in one call: .safetensors or .pt with model|module|state_dict, strict=False, and the packed-image
+        cache of controlar_amd/checkpoint.py (the second start from the same file restores the HIP weight images by plain copies)."""
+        from .checkpoint import load_checkpoint
+        self._ckpt = (path, cache_dir, use_cache)
+        sd = load_checkpoint(path)
+        res = self.load_state_dict(sd, strict=False)
+        self._ckpt = (path, cache_dir, use_cache)
+        return res
 
     def to(self, *args, **kw):
         for a in list(args) + list(kw.values()):
@@ -82,7 +101,12 @@ class Transformer:
         if self._engine is None:
             prec = "bf16" if self._dtype == torch.bfloat16 else "fp32"
             self._engine = Engine(self.cfg, prec, device=self._device)
-            self._engine.load_state_dict(self._sd, finalize=True)
+            ck = getattr(self, "_ckpt", None)
+            if ck is not None:
+                from .checkpoint import load_engine_from_checkpoints
+                self.cache_info = load_engine_from_checkpoints(self._engine, gpt_path=ck[0], cache_dir=ck[1], use_cache=ck[2])
+            else:
+                self._engine.load_state_dict(self._sd, finalize=True)
         return self._engine
 
     # generate.py:136-138 calls these two in sequence
@@ -118,10 +142,19 @@ class VQModel:
         self._sd: Dict[str, torch.Tensor] = {}
         self._engine: Optional[Engine] = None
 
-    def load_state_dict(self, sd, strict: bool = False):
+    def load_state_dict(self, sd, strict: bool = True):
+        """The reference loads the tokenizer strictly (sample_t2i.py:49).  Required here: the decode side; the encode side
+        (encoder.*, quant_conv.*) is optional as a group (it enables encode_indices) and complete if present."""
+        from .checkpoint import expected_vq_keys, key_report
+        exp = expected_vq_keys(self.vq, "decoder")
+        if any(k.startswith(("encoder.", "quant_conv.")) for k in sd):
+            exp = exp + expected_vq_keys(self.vq, "encoder")
+        missing, unexpected = key_report(exp, list(sd.keys()), ("quantize.codebook_used",))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for VQModel: Missing key(s): {missing[:8]} Unexpected key(s): {unexpected[:8]}")
         self._sd.update({k: v for k, v in sd.items() if torch.is_tensor(v)})
         self._engine = None
-        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
     def to(self, *args, **kw):
         for a in list(args) + list(kw.values()):

@@ -104,6 +104,17 @@ int car_load_tensor(car_ctx* ctx, const char* name, const void* ptr, const int64
 int car_finalize_weights(car_ctx* ctx);
 
 /*
+ * Packed-weight cache — the start-up cost of sample_t2i.py:64-83 / demo/model.py:66-75 (checkpoints re-read and re-loaded on every
+ * start, in the demo on every request).  car_export_packed writes every weight image of a FINALISED context (row-major
+ * operands, MFMA-fragment / e4m3 decode images, scales, conv layouts, host tables) to `path`; car_import_packed restores them
+ * by plain copies into a context created with the same car_config and finalises it.  The file is only valid for this
+ * library build (magic + car_config are checked); keying it on the checkpoint content is the caller's job
+ * (controlar_amd/checkpoint.py).
+ */
+int car_export_packed(car_ctx* ctx, const char* path);
+int car_import_packed(car_ctx* ctx, const char* path);
+
+/*
  * Control encoder + adapter MLP — replaces model.adapter(condition) + model.adapter_mlp(...)
  * (generate.py:136-138; dinov2_adapter.py:26-29).  img: [B,3,H,W] in [-1,1], dtype F32/BF16.
  * out (optional, may be NULL): [B,(H/16)(W/16),dim] in the context's element type; the result is
