@@ -327,11 +327,49 @@ __global__ void gn_apply_kernel(const void* x_, const float* stats, const void* 
         ET<T>::st((T*)y_ + i, v);
     }
 }
+// bf16, C a power of two <= 2048: 16-byte loads (8 channels per lane), the pixels of a chunk dealt round-robin to 256 / (C/8)
+// lane slots, slot sums folded in fixed order through LDS.  Same output as gn_partial_kernel (per-chunk per-channel sum, sum-sq).
+__global__ __launch_bounds__(256) void gn_partial_vec_kernel(const bf16_t* __restrict__ x_, float* __restrict__ part, int HW, int C) {
+    extern __shared__ float sh[];            // [256][16]: 8 sums + 8 square sums per thread
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const bf16_t* x = x_ + (long)b * HW * C;
+    const int p0 = chunk * GN_CHUNK, p1 = min(HW, p0 + GN_CHUNK);
+    const int cpv = C >> 3, nslot = 256 / cpv, v = threadIdx.x % cpv, slot = threadIdx.x / cpv;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int p = p0 + slot; p < p1; p += nslot) {
+        const uint4 u = *(const uint4*)(x + (long)p * C + v * 8);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = __uint_as_float(w[i] << 16), c = __uint_as_float(w[i] & 0xffff0000u);
+            s[2 * i] += a; q[2 * i] += a * a; s[2 * i + 1] += c; q[2 * i + 1] += c * c;
+        }
+    }
+    float* mine = sh + threadIdx.x * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mine[e] = s[e]; mine[8 + e] = q[e]; }
+    __syncthreads();
+    if (slot == 0) {
+        for (int k = 1; k < nslot; ++k) {
+            const float* o = sh + (k * cpv + v) * 16;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += o[e]; q[e] += o[8 + e]; }
+        }
+        float* o = part + ((long)b * nchunk + chunk) * 2 * C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[v * 8 + e] = s[e]; o[C + v * 8 + e] = q[e]; }
+    }
+}
+
 extern "C" void car_launch_groupnorm(int mode, const void* x, const void* gamma, const void* beta, void* y, float* part, float* stats,
                                      int B, int HW, int C, int G, float eps, int swish, hipStream_t st) {
     const int nchunk = (HW + GN_CHUNK - 1) / GN_CHUNK;
     const size_t shb = (2 * C + 512) * sizeof(float);
-    if (mode == 1) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
+    if (mode == 1 && C >= 8 && C <= 2048 && (C & (C - 1)) == 0)
+        hipLaunchKernelGGL(gn_partial_vec_kernel, dim3(nchunk, B), dim3(256), (size_t)256 * 16 * 4, st, (const bf16_t*)x, part, HW, C);
+    else if (mode == 1) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
     else hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, st, part, stats, nchunk, C, G, HW, eps);
     long total = (long)B * HW * C; int g = (int)((total + 255) / 256); if (g > 8192) g = 8192;
@@ -400,7 +438,72 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const void* x_, const voi
     const long hw = (long)H * W, o = b * 3 * hw + (long)y * W + x;
     out[o] = a0 + bias[0]; out[o + hw] = a1 + bias[1]; out[o + 2 * hw] = a2 + bias[2];
 }
+// bf16 fast path: the 3x3 C->3 convolution as ONE pass over the activation.  A workgroup owns a 16x16 output tile: for its
+// 18x18 halo of input pixels it computes the 27 per-tap partial products  Y[p][tap*3+o] = sum_c x[p][c] w[o][tap][c]  on the
+// matrix cores (A = 16 pixels x 32 channels straight from HBM, 16 B per lane; B = the 27 x C weights held in registers),
+// parks Y (fp32) in LDS, then every thread sums the 9 taps of its own pixel.  The activation is read 1.27x (halo) instead
+// of 9x through the caches, and the 3-wide output never occupies a 128-wide GEMM tile.
+__global__ __launch_bounds__(256) void conv_out_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int B, int H, int W, int C) {
+    __shared__ float ys[336 * 28];                     // 21 m-blocks of 16 halo pixels x 27 (+1 pad) partial products
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
+    const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16, b = blockIdx.z;
+    const int nkb = C >> 5;                            // <= 8 (C <= 256)
+    // B fragments: lane (q4, c16) holds w[n = nb*16 + c16][c = kb*32 + q4*8 .. +8], n = tap*3 + o (n >= 27: zero)
+    bf16x8 wf[2][8];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int n = nb * 16 + c16;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kb < nkb && n < 27) { const int o = n % 3, tap = n / 3; v = *(const uint4*)(w + ((long)(o * 9 + tap)) * C + kb * 32 + q4 * 8); }
+            wf[nb][kb] = *(const bf16x8*)&v;
+        }
+    }
+    const bf16_t* xb = x + (long)b * H * W * C;
+    for (int mb = wave; mb < 21; mb += 4) {
+        const int p = mb * 16 + c16;                   // halo pixel of this lane's A row
+        const int hy = p / 18, hx = p - hy * 18, yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+        const bool ok = p < 324 && yy >= 0 && yy < H && xx >= 0 && xx < W;      // zero padding of the conv input
+        const bf16_t* px = xb + ((long)yy * W + xx) * C + q4 * 8;
+        f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            if (kb < nkb) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) v = *(const uint4*)(px + kb * 32);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&v, wf[0][kb], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&v, wf[1][kb], a1, 0, 0, 0);
+            }
+        }
+        // D[row = pixel q4*4 + r][col = n]: n = c16 (a0) and 16 + c16 (a1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* d = ys + (mb * 16 + q4 * 4 + r) * 28;
+            d[c16] = a0[r];
+            if (c16 < 12) d[16 + c16] = a1[r];
+        }
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = tid & 15, y = ty0 + ly, xo = tx0 + lx;
+    if (y < H && xo < W) {
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* d = ys + ((ly + tap / 3) * 18 + lx + tap % 3) * 28 + tap * 3;
+            o0 += d[0]; o1 += d[1]; o2 += d[2];
+        }
+        const long hw = (long)H * W, o = (long)b * 3 * hw + (long)y * W + xo;
+        out[o] = o0 + bias[0]; out[o + hw] = o1 + bias[1]; out[o + 2 * hw] = o2 + bias[2];
+    }
+}
+
 extern "C" void car_launch_conv_out(int mode, const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int C, hipStream_t st) {
+    if (mode == 1 && C % 32 == 0 && C <= 256) {
+        hipLaunchKernelGGL(conv_out_mfma_kernel, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, bias, out, B, H, W, C);
+        return;
+    }
     const long npix = (long)B * H * W;
     const size_t shb = (size_t)27 * C * sizeof(float);
     if (mode == 1) hipLaunchKernelGGL(conv_out_kernel<bf16_t>, dim3((npix + 255) / 256), dim3(256), shb, st, x, w, bias, out, B, H, W, C);
