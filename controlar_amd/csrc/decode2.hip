@@ -57,6 +57,11 @@ struct GemmDP {
     const float* rope;    // [n_pos][32][2]
     const int* pos;
     int H, SA, dim;
+    // NORM kernels (M <= 16): X = RMSNorm of the residual stream, computed in the prologue of every workgroup (K = model dim):
+    //   v = gather ? emb[idx[m]] : h_in[m] ; (+ control token at *pos, gpt_t2i.py:466) ; workgroup 0 stores v to h_out if set ;
+    //   x = rnd(rnd(v * rsqrt(mean v^2 + eps)) * w)     — the arithmetic of rmsnorm2_kernel, gpt_t2i.py:193-198
+    const bf16_t* nh_in; const bf16_t* nemb; const int* nidx; bf16_t* nh_out; const bf16_t* nw; const bf16_t* nctrl;
+    int nadd, nT, n_tok; float ncs, neps;
 };
 
 // OCP e4m3fn bytes -> bf16 (exact: e4m3 is a subset of bf16).  lo/hi: 4 bytes each = 8 consecutive k of one row.
@@ -73,9 +78,16 @@ __device__ inline bf16x8 fp8x8_to_bf16x8_(unsigned lo, unsigned hi) {
 
 // F8 = 1: weight-only e4m3 (BASELINE config 5; the reference has no fp8 path): one 16-byte weight load carries the fragments
 // of TWO k-blocks, widened to bf16 in registers; the per-row scale multiplies the folded fp32 sum in the epilogue.
-template <int I, int J, int WAVES, int EPI, int F8>
+// NORM = 1 (J = 1, M <= 16: the latency-bound small-batch regime): the RMSNorm that produces X runs in the prologue of every
+// workgroup (16 rows x 2.5 KB from L2) while the first weight stages are already in flight, and X fragments come from LDS —
+// one dependent kernel per linear fewer than "norm kernel -> GEMM".
+template <int I, int J, int WAVES, int EPI, int F8, int NORM>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
-    extern __shared__ __attribute__((aligned(16))) float red[];       // [WAVES][I*J][64] f32x4
+    extern __shared__ __attribute__((aligned(16))) float red_all[];   // [NORM: 16 x (K+8) bf16] then [WAVES][I*J][64] f32x4
+    static_assert(!NORM || J == 1, "the fused-norm variant serves one m-block");
+    const int xs_ld = p.K + 8;                                         // bf16 elements per LDS row: 16-byte reads of 16 rows hit 16 distinct bank groups
+    bf16_t* xs = (bf16_t*)red_all;
+    float* red = NORM ? red_all + (16 * xs_ld) / 2 : red_all;
     constexpr int XPU = F8 ? 2 : 1;                                    // X chunks (k-blocks) per weight load unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nkb = p.K >> 5, nku = nkb / XPU, Mb = (p.M + 15) >> 4;
@@ -107,12 +119,19 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
             const u32x4* a = wp + ((long)i * nku + ku) * 64;
             w[i] = p.w_nt ? __builtin_nontemporal_load(a) : *a;
         }
+        if (!NORM) {
 #pragma unroll
-        for (int j = 0; j < J; ++j)
+            for (int j = 0; j < J; ++j)
 #pragma unroll
-            for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (j < jn) x[j * XPU + u] = xp[((long)j * nkb + ku * XPU + u) * 64]; }
+                for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (j < jn) x[j * XPU + u] = xp[((long)j * nkb + ku * XPU + u) * 64]; }
+        }
     };
-    auto compute = [&](const u32x4 (&w)[I], const u32x4 (&x)[J * XPU]) {
+    const bf16_t* xl = xs + (lane & 15) * xs_ld + (lane >> 4) * 8;     // NORM: this lane's row / k offset inside a k-block
+    auto compute = [&](const u32x4 (&w)[I], u32x4 (&x)[J * XPU], int ku) {
+        if (NORM) {
+#pragma unroll
+            for (int u = 0; u < XPU; ++u) x[u] = *(const u32x4*)(xl + (ku * XPU + u) * 32);
+        }
 #pragma unroll
         for (int i = 0; i < I; ++i) {
             if (F8) {
@@ -132,11 +151,53 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     const int nkw = ku_hi - ku_lo;
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) if (d < nkw) load(wr[d], xr[d], ku_lo + d);
+    if (NORM) {
+        // ---- prologue: one wave per row (the code of rmsnorm2_kernel), rows >= M are never stored downstream
+        const int D = p.K, ng = D >> 2;
+        for (int m = wave; m < p.M; m += WAVES) {
+            const bf16_t* src = p.nidx ? p.nemb + (long)p.nidx[m] * D : p.nh_in + (long)m * D;
+            const bf16_t* add = p.nadd ? p.nctrl + ((long)m * p.n_tok + (*p.pos - p.nT + 1)) * D : nullptr;
+            float val[8][4];
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int gi = lane + q * 64;
+                if (gi < ng) {
+                    const uint2 u = *(const uint2*)(src + gi * 4);
+                    float v[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+                    if (add) {
+                        const uint2 a = *(const uint2*)(add + gi * 4);
+                        const float c[4] = {__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e] + bf2f(f2bf(p.ncs * c[e]))));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { val[q][e] = v[e]; ss += v[e] * v[e]; }
+                }
+            }
+            const float rstd = rsqrtf(wave_sum(ss) / D + p.neps);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int gi = lane + q * 64;
+                if (gi < ng) {
+                    const int k = gi * 4;
+                    if (p.nh_out && blockIdx.x == 0) { uint2 u; u.x = pack_bf16x2(val[q][0], val[q][1]); u.y = pack_bf16x2(val[q][2], val[q][3]); *(uint2*)(p.nh_out + (long)m * D + k) = u; }
+                    const uint2 wu = *(const uint2*)(p.nw + k);
+                    const float w[4] = {__uint_as_float(wu.x << 16), __uint_as_float(wu.x & 0xffff0000u), __uint_as_float(wu.y << 16), __uint_as_float(wu.y & 0xffff0000u)};
+                    uint2 u;
+                    u.x = pack_bf16x2(bf2f(f2bf(val[q][0] * rstd)) * w[0], bf2f(f2bf(val[q][1] * rstd)) * w[1]);
+                    u.y = pack_bf16x2(bf2f(f2bf(val[q][2] * rstd)) * w[2], bf2f(f2bf(val[q][3] * rstd)) * w[3]);
+                    *(uint2*)(xs + m * xs_ld + k) = u;
+                }
+            }
+        }
+        __syncthreads();
+    }
     for (int base = 0; base < nkw; base += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             if (base + d < nkw) {                                     // wave-uniform
-                compute(wr[d], xr[d]);
+                compute(wr[d], xr[d], ku_lo + base + d);
                 if (base + d + DEPTH < nkw) load(wr[d], xr[d], ku_lo + base + d + DEPTH);
             }
         }
@@ -231,18 +292,22 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     }
 }
 
-template <int I, int J, int WAVES, int F8>
+template <int I, int J, int WAVES, int F8, int NORM>
 static void launch_gemm_ij(const GemmDP& p, int epi, hipStream_t st) {
     const int Mb = (p.M + 15) / 16, MT = (Mb + J - 1) / J, NT = p.N / (16 * I);
     const dim3 g(NT * MT), b(WAVES * 64);
-    const size_t sh = (size_t)WAVES * I * J * 64 * 16;
-    static bool attr[4] = {false, false, false, false};
+    const size_t sh = (size_t)WAVES * I * J * 64 * 16 + (NORM ? (size_t)16 * (p.K + 8) * 2 : 0);
+    static size_t attr[4] = {0, 0, 0, 0};
 #define LG(E)                                                                                                                   \
     do {                                                                                                                        \
-        if (sh > 48 * 1024 && !attr[E]) { (void)hipFuncSetAttribute((const void*)dec_gemm_kernel<I, J, WAVES, E, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr[E] = true; } \
-        hipLaunchKernelGGL((dec_gemm_kernel<I, J, WAVES, E, F8>), g, b, sh, st, p);                                                  \
+        if (sh > 48 * 1024 && sh > attr[E]) { (void)hipFuncSetAttribute((const void*)dec_gemm_kernel<I, J, WAVES, E, F8, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr[E] = sh; } \
+        hipLaunchKernelGGL((dec_gemm_kernel<I, J, WAVES, E, F8, NORM>), g, b, sh, st, p);                                        \
     } while (0)
-    if (epi == EPI_LOGITS) LG(EPI_LOGITS); else if (epi == EPI_RESID) LG(EPI_RESID); else if (epi == EPI_SWIGLU) LG(EPI_SWIGLU); else LG(EPI_QKV);
+    if (NORM) {                      // the residual-add epilogue never follows a norm (gpt_t2i.py:305-306)
+        if (epi == EPI_LOGITS) LG(EPI_LOGITS); else if (epi == EPI_SWIGLU) LG(EPI_SWIGLU); else LG(EPI_QKV);
+    } else {
+        if (epi == EPI_LOGITS) LG(EPI_LOGITS); else if (epi == EPI_RESID) LG(EPI_RESID); else if (epi == EPI_SWIGLU) LG(EPI_SWIGLU); else LG(EPI_QKV);
+    }
 #undef LG
 }
 
@@ -250,18 +315,22 @@ static void launch_gemm_ij(const GemmDP& p, int epi, hipStream_t st) {
 extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st) {
     if (epi == EPI_SWIGLU && cfg < 200) return -1;       // the (a, c) pair needs two adjacent row-blocks in one tile
     if (p->N % (16 * (cfg / 100)) || p->K % 32) return -1;
-    if (p->wscale) {
-        if (p->K % 64) return -1;
+    if (p->wscale && p->K % 64) return -1;
+    const bool f8 = p->wscale != nullptr;
+    if (p->nw) {                                         // fused-norm variant: one m-block
+        if (p->M > 16 || (cfg / 10) % 10 != 1 || epi == EPI_RESID || p->K > 2048) return -1;
         switch (cfg) {
-#define CASE(I, J) case I * 100 + J * 10: launch_gemm_ij<I, J, 4, 1>(*p, epi, st); break; case I * 100 + J * 10 + 1: launch_gemm_ij<I, J, 8, 1>(*p, epi, st); break;
-            CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
+#define CASE(I) case I * 100 + 10: if (f8) launch_gemm_ij<I, 1, 4, 1, 1>(*p, epi, st); else launch_gemm_ij<I, 1, 4, 0, 1>(*p, epi, st); break; \
+                case I * 100 + 11: if (f8) launch_gemm_ij<I, 1, 8, 1, 1>(*p, epi, st); else launch_gemm_ij<I, 1, 8, 0, 1>(*p, epi, st); break;
+            CASE(1) CASE(2) CASE(4)
 #undef CASE
             default: return -1;
         }
         return 0;
     }
     switch (cfg) {
-#define CASE(I, J) case I * 100 + J * 10: launch_gemm_ij<I, J, 4, 0>(*p, epi, st); break; case I * 100 + J * 10 + 1: launch_gemm_ij<I, J, 8, 0>(*p, epi, st); break;
+#define CASE(I, J) case I * 100 + J * 10: if (f8) launch_gemm_ij<I, J, 4, 1, 0>(*p, epi, st); else launch_gemm_ij<I, J, 4, 0, 0>(*p, epi, st); break; \
+                   case I * 100 + J * 10 + 1: if (f8) launch_gemm_ij<I, J, 8, 1, 0>(*p, epi, st); else launch_gemm_ij<I, J, 8, 0, 0>(*p, epi, st); break;
         CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
 #undef CASE
         default: return -1;

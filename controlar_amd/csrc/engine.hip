@@ -43,6 +43,8 @@ struct GemmDP {
     const bf16_t* W; const bf16_t* X; int M, N, K; int w_nt; const float* wscale;
     bf16_t* h; bf16_t* outp; float* outf;
     bf16_t* qout; bf16_t* kc; bf16_t* vc; const float* rope; const int* pos; int H, SA, dim;
+    const bf16_t* nh_in; const bf16_t* nemb; const int* nidx; bf16_t* nh_out; const bf16_t* nw; const bf16_t* nctrl;
+    int nadd, nT, n_tok; float ncs, neps;
 };
 struct Attn2P {
     const bf16_t* q; const bf16_t* kc; const bf16_t* vc; const int* pos; const unsigned char* mask; const int* jmin;
@@ -861,7 +863,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     const size_t kv_layer = (size_t)b_total * Hn * SA * 64, kv_off = (size_t)b0 * Hn * SA * 64;
     bf16_t* h = (bf16_t*)sb.h + (size_t)b0 * D;
     const bool f8 = g.decode_weight_fp8 != 0;
-    int nk = 0;
+    int nk = 0, bad_cfg = 0;
     auto gemm = [&](const std::string& wname, const bf16_t* X, int N, int K, int epi, GemmDP gp_) {
         GemmDP p = gp_;
         p.W = (const bf16_t*)Wp(c, wname + (f8 ? "#pk8" : "#pk")); p.X = X; p.M = b; p.N = N; p.K = K;
@@ -869,12 +871,29 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         const int cfg = car_pick_gemm_cfg(b, N, K, epi);
         const int J = (cfg / 10) % 10, Mb = (b + 15) / 16;
         p.w_nt = (Mb + J - 1) / J == 1;
-        car_launch_dec_gemm_cfg(&p, epi, cfg, st); ++nk;
+        if (car_launch_dec_gemm_cfg(&p, epi, cfg, st)) bad_cfg = cfg;
+        ++nk;
     };
     GemmDP z; memset(&z, 0, sizeof(z));
+    // tiny chains (<= 4 rows): the latency-bound regime (BASELINE configs 2, 4).  The two RMSNorms of a layer and the final norm run
+    // in the prologue of the GEMM that consumes them (dec_gemm NORM variant): 6 kernels per layer instead of 8.  Measured on MI355X
+    // (profiles/r02_small_batch.txt): 1.55 -> 1.51 ms/step at 2 rows, but SLOWER from 8 rows up (every workgroup repeats the norm of
+    // all rows: 1.60 -> 1.67 ms at 8, 1.69 -> 2.07 ms at 16) — the step is bound by per-kernel latency chains, not by kernel count.
+    const bool fuse_norm = b <= 4 && D <= 2048 && !getenv("CAR_NO_SMALL_FUSE");
+    bf16_t* hc = h;                                                  // the residual stream; ping-pongs with `halt` when a control token is added
+    bf16_t* halt = (bf16_t*)sb.xn + (size_t)b0 * D;                  // (the prefill's xn buffer is idle during decode)
+    auto norm_fields = [&](GemmDP& q, const std::string& wname, int l, bool first_of_layer) {
+        q.nw = (const bf16_t*)Wp(c, wname); q.neps = g.norm_eps; q.nh_in = hc; q.pos = gr.pos;
+        if (first_of_layer && l == 0) { q.nemb = (const bf16_t*)Wp(c, "tok_embeddings.weight"); q.nidx = sb.cur + b0; q.nh_out = h; }
+        if (first_of_layer && use_ctrl && l % li == 0 && l / li < 3) {
+            q.nadd = 1; q.nctrl = (const bf16_t*)c->ctrl[l / li].p + (size_t)b0 * n_tok * D; q.nT = T; q.n_tok = n_tok; q.ncs = cs;
+            q.nh_out = l == 0 ? h : (hc == h ? halt : h);            // never in place: every workgroup re-reads the un-added stream
+        }
+    };
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
-        {   // [token gather at layer 0] (+ control add at layers 0, n/3, 2n/3) -> h ; attention_norm -> xn (packed)
+        bf16_t* kc = (bf16_t*)c->kv.p + (size_t)(2 * l) * kv_layer + kv_off; bf16_t* vc = (bf16_t*)c->kv.p + (size_t)(2 * l + 1) * kv_layer + kv_off;
+        if (!fuse_norm) {   // [token gather at layer 0] (+ control add at layers 0, n/3, 2n/3) -> h ; attention_norm -> xn (packed)
             Norm2P np; memset(&np, 0, sizeof(np));
             np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
             if (l == 0) { np.emb = (const bf16_t*)Wp(c, "tok_embeddings.weight"); np.idx = sb.cur + b0; np.h_out = h; }
@@ -883,10 +902,11 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             }
             car_launch_rmsnorm2(&np, b, st); ++nk;
         }
-        bf16_t* kc = (bf16_t*)c->kv.p + (size_t)(2 * l) * kv_layer + kv_off; bf16_t* vc = (bf16_t*)c->kv.p + (size_t)(2 * l + 1) * kv_layer + kv_off;
         {
             GemmDP q = z; q.qout = fb.q; q.kc = kc; q.vc = vc; q.rope = c->rope; q.pos = gr.pos; q.H = Hn; q.SA = SA; q.dim = D;
+            if (fuse_norm) { norm_fields(q, L + "attention_norm.weight", l, true); }
             gemm(L + "attention.wqkv.weight", fb.xn, 3 * D, D, EPI_QKV, q);
+            if (fuse_norm && q.nh_out) hc = q.nh_out;
         }
         {
             Attn2P ap; memset(&ap, 0, sizeof(ap));
@@ -894,25 +914,26 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             ap.out = fb.att; ap.part = fb.attn_part; ap.H = Hn; ap.SA = SA; ap.T = T; ap.dim = D; ap.nsplit = nsplit; ap.out_packed = 1;
             car_launch_dec_attn2_var(&ap, b, gr.attn_variant, gr.attn_lds_pad, st); nk += nsplit > 1 ? 2 : 1;
         }
-        { GemmDP q = z; q.h = h; gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
-        {
+        { GemmDP q = z; q.h = hc; gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
+        if (!fuse_norm) {
             Norm2P np; memset(&np, 0, sizeof(np));
             np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps;
             car_launch_rmsnorm2(&np, b, st); ++nk;
         }
-        { GemmDP q = z; q.outp = fb.mid; gemm(L + "feed_forward.w13.weight", fb.xn, 2 * Fh, D, EPI_SWIGLU, q); }
-        { GemmDP q = z; q.h = h; gemm(L + "feed_forward.w2.weight", fb.mid, D, Fh, EPI_RESID, q); }
+        { GemmDP q = z; q.outp = fb.mid; if (fuse_norm) norm_fields(q, L + "ffn_norm.weight", l, false); gemm(L + "feed_forward.w13.weight", fb.xn, 2 * Fh, D, EPI_SWIGLU, q); }
+        { GemmDP q = z; q.h = hc; gemm(L + "feed_forward.w2.weight", fb.mid, D, Fh, EPI_RESID, q); }
     }
-    {
+    if (!fuse_norm) {
         Norm2P np; memset(&np, 0, sizeof(np));
         np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps;
         car_launch_rmsnorm2(&np, b, st); ++nk;
     }
-    { GemmDP q = z; q.outf = fb.logits; gemm("output.weight", fb.xn, V, D, EPI_LOGITS, q); }
+    { GemmDP q = z; q.outf = fb.logits; if (fuse_norm) norm_fields(q, "norm.weight", g.n_layer, false); gemm("output.weight", fb.xn, V, D, EPI_LOGITS, q); }
     car_launch_advance(gr.pos, gr.step, st); ++nk;
     SampleP sp = gr.sp; sp.logits = fb.logits; sp.logits_ks = 0; sp.round_bf16 = 0;
     car_launch_sample_greedy(&sp, st); ++nk;
     c->n_dec_kernels = nk;
+    if (bad_cfg) FAIL(c, "decode GEMM: tile configuration %d rejected for this model's dimensions (b=%d, dim=%d, ffn=%d, vocab=%d)", bad_cfg, b, D, Fh, V);
     return 0;
 }
 
@@ -1210,18 +1231,19 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     const unsigned char* fmask = emb_mask ? (const unsigned char*)c->maskb.p : nullptr;      // no text-pad mask: nothing to test per position
     const int* fjmin = emb_mask ? jmin : nullptr;
     bool capturing = false;
+    int step_rc = 0;
     auto step_fn = [&]() {
         if (!fast) { enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st); return; }
         if (NG >= 2 && capturing) {      // fork NG-1 extra branches inside the capture
             (void)hipEventRecord(c->ev_fork, st);
             for (int gi = 1; gi < NG; ++gi) (void)hipStreamWaitEvent(c->streamx[gi - 1], c->ev_fork, 0);
-            enqueue_decode_step_fast(c, sb, grp[0], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, st);
+            step_rc |= enqueue_decode_step_fast(c, sb, grp[0], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, st);
             for (int gi = 1; gi < NG; ++gi) {
-                enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, c->streamx[gi - 1]);
+                step_rc |= enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, c->streamx[gi - 1]);
                 (void)hipEventRecord(c->ev_joinx[gi - 1], c->streamx[gi - 1]); (void)hipStreamWaitEvent(st, c->ev_joinx[gi - 1], 0);
             }
         } else {
-            for (int gi = 0; gi < NG; ++gi) enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, st);
+            for (int gi = 0; gi < NG; ++gi) step_rc |= enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, st);
         }
         c->n_dec_kernels *= NG;
     };
@@ -1256,6 +1278,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             for (int i = 0; i < nsteps; ++i) step_fn();
         }
     }
+    if (step_rc) { fence_out(c, caller); return -1; }        // c->err was set by the step builder
     HIPCHK(c, hipEventRecord(c->ev_t2, st));
     HIPCHK(c, hipMemcpyAsync(out_tokens, c->tok_out.p, (size_t)B * n_new * 4, hipMemcpyDeviceToDevice, st));
     fence_out(c, caller);

@@ -229,6 +229,37 @@ static void test_norm() {
     CK(hipFree(dH)); CK(hipFree(dWn)); CK(hipFree(dX));
 }
 
+// ------------------------------------------------------------------------------------------------ fused-norm GEMM (M <= 16)
+static void test_gemm_norm() {
+    const int M = 5, D = 256, N = 512;
+    std::vector<bf16_t> h((size_t)M * D), w(D), ctrl((size_t)M * 3 * D); for (auto& v : h) v = f2bf(frand() * 3.f); for (auto& v : w) v = f2bf(1.f + 0.1f * frand()); for (auto& v : ctrl) v = f2bf(frand());
+    std::vector<float> W((size_t)N * D); for (auto& v : W) v = rb(frand() * 0.1f);
+    auto wp = pack_rows(W, N, D);
+    bf16_t* dH = dalloc<bf16_t>(h.size()); h2d(dH, h); bf16_t* dWn = dalloc<bf16_t>(D); h2d(dWn, w); bf16_t* dC = dalloc<bf16_t>(ctrl.size()); h2d(dC, ctrl);
+    bf16_t* dW = dalloc<bf16_t>(wp.size()); h2d(dW, wp);
+    bf16_t* dX = dalloc<bf16_t>((size_t)16 * D); bf16_t* dH1 = dalloc<bf16_t>(h.size()); bf16_t* dH2 = dalloc<bf16_t>(h.size());
+    float* dO1 = dalloc<float>((size_t)M * N); float* dO2 = dalloc<float>((size_t)M * N);
+    int pos = 41; int* dPos = dalloc<int>(1); CK(hipMemcpy(dPos, &pos, 4, hipMemcpyHostToDevice));      // control token index pos - T + 1 = 2 with T = 40
+    for (int add = 0; add < 2; ++add) for (int cfg : {110, 111, 210, 411}) {
+        // reference path: rmsnorm2 -> packed xn -> dec_gemm
+        Norm2P np; memset(&np, 0, sizeof(np)); np.h_in = dH; np.xn = dX; np.w = dWn; np.D = D; np.eps = 1e-5f; np.h_out = dH1;
+        if (add) { np.add = 1; np.ctrl = dC; np.pos = dPos; np.T = 40; np.n_tok = 3; np.cs = 0.6f; }
+        car_launch_rmsnorm2(&np, M, 0);
+        GemmDP p; memset(&p, 0, sizeof(p)); p.W = dW; p.X = dX; p.M = M; p.N = N; p.K = D; p.outf = dO1;
+        car_launch_dec_gemm_cfg(&p, EPI_LOGITS, cfg, 0);
+        GemmDP q; memset(&q, 0, sizeof(q)); q.W = dW; q.M = M; q.N = N; q.K = D; q.outf = dO2; q.nh_in = dH; q.nw = dWn; q.neps = 1e-5f; q.nh_out = dH2; q.pos = dPos;
+        if (add) { q.nadd = 1; q.nctrl = dC; q.nT = 40; q.n_tok = 3; q.ncs = 0.6f; }
+        CK(hipMemset(dO2, 0xff, (size_t)M * N * 4));
+        if (car_launch_dec_gemm_cfg(&q, EPI_LOGITS, cfg, 0)) { printf("fused-norm cfg %d rejected\n", cfg); ++g_fail; continue; }
+        CK(hipDeviceSynchronize());
+        auto o1 = d2h(dO1, (size_t)M * N), o2 = d2h(dO2, (size_t)M * N); auto h1 = d2h(dH1, h.size()), h2 = d2h(dH2, h.size());
+        double e = 0; for (size_t i = 0; i < o1.size(); ++i) e = std::max(e, std::fabs((double)o1[i] - o2[i]));
+        double eh = 0; for (size_t i = 0; i < h1.size(); ++i) eh = std::max(eh, std::fabs((double)bf2f(h1[i]) - bf2f(h2[i])));
+        char nm[96]; snprintf(nm, sizeof(nm), "dec_gemm fused-norm cfg %d add=%d vs rmsnorm2 + dec_gemm (bit-exact)", cfg, add); report(nm, e + eh, 0.0);
+    }
+    for (void* q : {(void*)dH, (void*)dWn, (void*)dC, (void*)dW, (void*)dX, (void*)dH1, (void*)dH2, (void*)dO1, (void*)dO2, (void*)dPos}) CK(hipFree(q));
+}
+
 // ------------------------------------------------------------------------------------------------ timing
 __global__ void fill_kernel(unsigned* p, size_t n, unsigned seed) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; const size_t st = (size_t)gridDim.x * blockDim.x;
@@ -338,6 +369,7 @@ int main(int argc, char** argv) {
     const bool noperf = argc > 1 && !strcmp(argv[1], "check");
     test_gemm();
     test_norm();
+    test_gemm_norm();
     const AttnCase cases[] = {
         {3, 2, 40, 40, 1, 0, 1, 0}, {3, 2, 40, 63, 1, 1, 1, 0}, {3, 2, 40, 64, 1, 1, 1, 0}, {3, 2, 40, 250, 1, 1, 1, 0}, {3, 2, 40, 250, 4, 1, 1, 0}, {20, 2, 40, 131, 2, 0, 1, 0},
         {3, 2, 40, 97, 1, 1, 2, 0}, {3, 2, 40, 97, 4, 1, 2, 0}, {2, 1, 1, 1, 1, 1, 0, 0}, {2, 1, 1, 33, 16, 1, 0, 0}, {17, 3, 120, 600, 1, 1, 1, 0}, {5, 2, 120, 1143, 1, 1, 1, 0},
