@@ -91,4 +91,7 @@ struct GemmP {
     int bias_mode, act, out_f32, swiglu;
     // AMODE_CONV3: A is NHWC [B,Hin,Win,Cin]; output grid Ho x Wo (= Hin<<ups); K = 9*Cin; M = B*Ho*Wo
     int Ho, Wo, Cin, ups;
+    int patch;            // AMODE_CONV3, bf16 kernels: GEMM rows enumerate the output in 16x16 spatial patches (Ho, Wo multiples of 16) so that a
+                          // tile's nine taps re-read an 18x18 halo that stays in L2, instead of three full image rows
+    const void* zero;     // >= 16 zero bytes in device memory: source of padded / out-of-range chunks of the LDS-DMA loader (set by car_launch_gemm)
 };

@@ -1356,6 +1356,7 @@ struct VqOps {
     void conv3(const void* x, void* y, const std::string& name, int nb, int Ho, int Wo, int Cin, int Cout, int ups, const void* R, int amode = AMODE_CONV3) const {
         GemmP q = gp(x, 0, Wp(c, name + ".weight"), 9 * (long)Cin, y, Cout, nb * Ho * Wo, Cout, 9 * Cin);
         q.bias = Wp(c, name + ".bias"); q.bias_mode = BIAS_N; q.Ho = Ho; q.Wo = Wo; q.Cin = Cin; q.ups = ups; q.R = R; q.ldr = Cout;
+        q.patch = 1;        // 16x16 spatial patch order of the GEMM rows where the launcher can use it (bf16, Ho and Wo multiples of 16)
         car_launch_gemm(mode, amode, &q, st);
     }
     void conv1(const void* x, void* y, const std::string& name, int M, int Cin, int Cout, const void* R) const {

@@ -9,7 +9,7 @@
 #include "car_common.h"
 
 template <typename T>
-__device__ inline float epi_value(const GemmP& p, const T* bias, const T* scale, const T* R, long zR, int m, int n, float v) {
+__device__ inline float epi_value(const GemmP& p, const T* bias, const T* scale, const T* R, long zR, int m, long mrow, int n, float v) {
     v *= p.alpha;
     if (p.bias_mode == BIAS_N) v += ET<T>::ld(bias + n);
     else if (p.bias_mode == BIAS_M) v += ET<T>::ld(bias + m);
@@ -18,22 +18,35 @@ __device__ inline float epi_value(const GemmP& p, const T* bias, const T* scale,
     else if (p.act == ACT_GELU_TANH) v = ET<T>::rnd(gelu_tanh_f(v));
     else if (p.act == ACT_SILU) v = ET<T>::rnd(silu_f(v));
     if (scale) v = ET<T>::rnd(v * ET<T>::ld(scale + n));
-    if (R) v = ET<T>::rnd(v + ET<T>::ld(R + zR + (long)m * p.ldr + n));
+    if (R) v = ET<T>::rnd(v + ET<T>::ld(R + zR + mrow * p.ldr + n));
     return v;
 }
 
 // ---- A-operand row descriptor (per thread, constant over the K loop)
 struct ARow { long base; int y, x; bool ok; };
 
-struct Geo { int M, Cin, Ho, Wo, ups; long lda; };
+struct Geo { int M, Cin, Ho, Wo, ups; long lda; int patch; };
+// patch order: m = ((b * (Ho/16) + ty) * (Wo/16) + tx) * 256 + py * 16 + px  ->  pixel (b, ty*16 + py, tx*16 + px)
+__device__ inline void patch_decode(int Ho, int Wo, int m, int& b, int& y, int& x) {
+    const int tw = Wo >> 4, th = Ho >> 4, tile = m >> 8, within = m & 255;
+    b = tile / (tw * th); const int t2 = tile - b * (tw * th), ty = t2 / tw, tx = t2 - ty * tw;
+    y = ty * 16 + (within >> 4); x = tx * 16 + (within & 15);
+}
+// row of C / R that GEMM row m addresses (the NHWC pixel index under patch order, m itself otherwise)
+__device__ inline long out_row(const GemmP& p, int m) {
+    if (!p.patch) return m;
+    int b, y, x; patch_decode(p.Ho, p.Wo, m, b, y, x);
+    return ((long)b * p.Ho + y) * p.Wo + x;
+}
 template <int AMODE>
 __device__ inline ARow make_arow(const Geo p, int m) {
     ARow r; r.ok = m < p.M; r.base = 0; r.y = 0; r.x = 0;
     if (AMODE == AMODE_PLAIN) { r.base = (long)m * p.lda; }
     else {
         const int hw = p.Ho * p.Wo;
-        const int b = m / hw, rem = m - b * hw;
+        int b = m / hw; const int rem = m - b * hw;
         r.y = rem / p.Wo; r.x = rem - r.y * p.Wo;
+        if (AMODE == AMODE_CONV3 && p.patch) patch_decode(p.Ho, p.Wo, m, b, r.y, r.x);
         if (AMODE == AMODE_CONV3S2) r.base = (long)b * (p.Ho * 2) * (p.Wo * 2);
         else r.base = (long)b * (p.Ho >> p.ups) * (p.Wo >> p.ups);   // in pixels
     }
@@ -78,7 +91,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 
     // load assignment: 2 A chunks + 2 W chunks of 16 B per thread per k-tile
     const int lrow0 = tid >> 2, lrow1 = lrow0 + 64, lkc = (tid & 3) * 8;
-    const Geo geo = { p.M, p.Cin, p.Ho, p.Wo, p.ups, p.lda };
+    const Geo geo = { p.M, p.Cin, p.Ho, p.Wo, p.ups, p.lda, p.patch };
     const ARow ar0 = make_arow<AMODE>(geo, m0 + lrow0), ar1 = make_arow<AMODE>(geo, m0 + lrow1);
     const bool wok0 = (n0 + lrow0) < p.N, wok1 = (n0 + lrow1) < p.N;
     const bf16_t* w0p = W + (long)(n0 + lrow0) * p.ldw + lkc;
@@ -152,18 +165,284 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
                 if (m < p.M && n < p.N) {
                     const float a1 = bf2f(f2bf(strip[rr * 68 + src])), c3 = bf2f(f2bf(strip[rr * 68 + src + 16]));
                     const float sl = bf2f(f2bf(silu_f(a1)));
-                    ((bf16_t*)p.C)[zC + (long)m * p.ldc + (nb >> 1) + c] = f2bf(sl * c3);
+                    ((bf16_t*)p.C)[zC + out_row(p, m) * p.ldc + (nb >> 1) + c] = f2bf(sl * c3);
                 }
             }
         } else {
             for (int rr = 0; rr < 16; ++rr) {
                 const int m = mb + rr, n = nb + lane;
                 if (m < p.M && n < p.N) {
-                    const float v = epi_value<bf16_t>(p, bias, scale, R, zR, m, n, strip[rr * 68 + lane]);
-                    if (out_f32) ((float*)p.C)[zC + (long)m * p.ldc + n] = v;
-                    else ((bf16_t*)p.C)[zC + (long)m * p.ldc + n] = f2bf(v);
+                    const long mr = out_row(p, m);
+                    const float v = epi_value<bf16_t>(p, bias, scale, R, zR, m, mr, n, strip[rr * 68 + lane]);
+                    if (out_f32) ((float*)p.C)[zC + mr * p.ldc + n] = v;
+                    else ((bf16_t*)p.C)[zC + mr * p.ldc + n] = f2bf(v);
                 }
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =========================================================================== bf16 MFMA, LDS-DMA staged (large-M GEMMs / convs)
+// 256x128x64 tiles, 8 waves (4x2) x (4x4) fragments of v_mfma_f32_16x16x32_bf16, THREE 48-KiB LDS stages filled by
+// global_load_lds (16 B per lane: no staging registers, no ds_write pass).  Stage t+2 is issued while stage t is consumed and
+// stage t+1 is still in flight: the per-wave wait is a counted vmcnt (one stage = 6 DMA pieces per wave may stay outstanding)
+// followed by a raw s_barrier — __syncthreads() would drain the DMA queue (cdna_hip_programming.md §5).  A stage row is
+// 64 k = 8 chunks of 16 B; chunk c of row r is stored at slot c ^ (r & 7): the DMA destination is lane-linear, so the swizzle is
+// applied to the per-lane GLOBAL address, and the fragment reads (16 rows x one chunk per ds_read_b128 group) spread over the
+// bank groups.  Padded taps of the implicit-GEMM conv, rows >= M and weight rows >= N read a zero page.
+// Requirements: K % 64 == 0, 16-byte aligned rows; conv: Cin % 64 == 0.  Used when the grid has >= 1 tile per CU.
+#define G2_BM 256
+#define G2_BK 64
+#define G2_NS 3
+#define G2_STAGE ((G2_BM + BN) * G2_BK)          // bf16 elements per stage
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int AMODE>
+__global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem2[];                   // 3 x 48 KiB
+#define S2A(buf) (smem2 + (buf) * G2_STAGE)
+#define S2B(buf) (smem2 + (buf) * G2_STAGE + G2_BM * G2_BK)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z, z0 = z / p.nb1, z1 = z - z0 * p.nb1;
+    const bf16_t* A = (const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1;
+    const bf16_t* W = (const bf16_t*)p.W + z0 * p.sW0 + z1 * p.sW1;
+    const long zC = z0 * p.sC0 + z1 * p.sC1, zR = z0 * p.sR0 + z1 * p.sR1;
+    const int m0 = blockIdx.y * G2_BM, n0 = blockIdx.x * BN;
+    const Geo geo = { p.M, p.Cin, p.Ho, p.Wo, p.ups, p.lda, p.patch };
+    // loader: wave w, pass i covers tile rows i*64 + w*8 .. +8; lane = (row-in-8, slot); global chunk = slot ^ row-in-8
+    const int lr = lane >> 3, gchunk = ((lane & 7) ^ lr) * 8;
+    ARow ar[4]; const bf16_t* wrow[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ar[i] = make_arow<AMODE>(geo, m0 + i * 64 + wave * 8 + lr);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int r = i * 64 + wave * 8 + lr; wrow[i] = (n0 + r) < p.N ? W + (long)(n0 + r) * p.ldw + gchunk : nullptr; }
+    const bf16_t* zero = (const bf16_t*)p.zero;
+    // K position of the NEXT stage to issue, kept incrementally (stages are issued in increasing k order): no divisions per step.
+    // conv: k = tap * Cin + c0, tap = (dy+1)*3 + (dx+1); Cin % 64 == 0 so a stage never straddles two taps.
+    int k_next = 0, c0 = 0, dy = -1, dx = -1;
+    const int Wi = p.Wo >> p.ups;
+    auto issue = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* src = zero;
+            if (AMODE == AMODE_PLAIN) { if (ar[i].ok) src = A + ar[i].base + k_next + gchunk; }
+            else {
+                const int yy = ar[i].y + dy, xx = ar[i].x + dx;
+                if (ar[i].ok && yy >= 0 && yy < p.Ho && xx >= 0 && xx < p.Wo)
+                    src = A + (ar[i].base + (long)(yy >> p.ups) * Wi + (xx >> p.ups)) * p.Cin + c0 + gchunk;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(S2A(buf) + (i * 64 + wave * 8) * G2_BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* src = wrow[i] ? wrow[i] + k_next : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(S2B(buf) + (i * 64 + wave * 8) * G2_BK), 16, 0, 0);
+        }
+        k_next += G2_BK; c0 += G2_BK;
+        if (AMODE != AMODE_PLAIN && c0 == p.Cin) { c0 = 0; if (++dx == 2) { dx = -1; ++dy; } }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = p.K / G2_BK;
+    const int fr = lane & 15, fq = lane >> 4;
+    issue(0);
+    if (nk > 1) issue(1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's 6 pieces of stage kt have landed; stage kt+1 (6 more) may still be in flight
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // ... so have all other waves'; and everyone is done reading the stage consumed at kt-1
+        if (kt + 2 < nk) issue(buf >= 1 ? buf - 1 : G2_NS - 1);              // stage kt+2 -> buffer (kt+2) % 3 == (kt-1) % 3, free now
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int r = wm * 64 + i * 16 + fr; a[i] = *(const bf16x8*)(S2A(buf) + r * G2_BK + (((kk * 4 + fq) ^ (r & 7)) << 3)); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int r = wn * 64 + j * 16 + fr; b[j] = *(const bf16x8*)(S2B(buf) + r * G2_BK + (((kk * 4 + fq) ^ (r & 7)) << 3)); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        buf = buf + 1 == G2_NS ? 0 : buf + 1;
+    }
+    __syncthreads();                              // the epilogue strips reuse the stage memory
+
+    // ---- epilogue (same as gemm_bf16_kernel): 16x64 fp32 strips through LDS, rolled per-element epilogue, row-contiguous stores
+    const bf16_t* bias = (const bf16_t*)p.bias; const bf16_t* scale = (const bf16_t*)p.scale; const bf16_t* R = (const bf16_t*)p.R;
+    float* strip = (float*)smem2 + wave * (16 * 68);
+    const int swiglu = p.swiglu, out_f32 = p.out_f32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 q = acc[i][j];
+            float* d = strip + ((lane >> 4) * 4) * 68 + j * 16 + fr;
+            d[0] = q[0]; d[68] = q[1]; d[136] = q[2]; d[204] = q[3];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int mb = m0 + wm * 64 + i * 16, nb = n0 + wn * 64;
+        if (swiglu) {
+            const int c = lane & 31, src = (c >> 4) * 32 + (c & 15);
+            for (int rr = (lane >> 5); rr < 16; rr += 2) {
+                const int m = mb + rr, n = nb + src;
+                if (m < p.M && n < p.N) {
+                    const float a1 = bf2f(f2bf(strip[rr * 68 + src])), c3 = bf2f(f2bf(strip[rr * 68 + src + 16]));
+                    const float sl = bf2f(f2bf(silu_f(a1)));
+                    ((bf16_t*)p.C)[zC + out_row(p, m) * p.ldc + (nb >> 1) + c] = f2bf(sl * c3);
+                }
+            }
+        } else {
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = mb + rr, n = nb + lane;
+                if (m < p.M && n < p.N) {
+                    const long mr = out_row(p, m);
+                    const float v = epi_value<bf16_t>(p, bias, scale, R, zR, m, mr, n, strip[rr * 68 + lane]);
+                    if (out_f32) ((float*)p.C)[zC + mr * p.ldc + n] = v;
+                    else ((bf16_t*)p.C)[zC + mr * p.ldc + n] = f2bf(v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =========================================================================== 3x3 conv with an LDS-resident halo (VQ decoder)
+// The nine taps of a 3x3 convolution re-read every input pixel nine times; as an implicit GEMM fed from global memory that is
+// 590 KB of L2/fabric traffic per 128x128x1152 tile, and the fabric (~6 TB/s) — not the matrix cores — bounds the kernel at
+// ~15 % of the MFMA peak (profiles/r02_*trace*: 376 TFLOP/s on the 128->128 conv at 512x512).  Here a workgroup owns one
+// 16x16 output patch x 128 output channels: the patch's input halo (18x18 pixels, or 10x10 under the folded nearest x2
+// upsample, vq_model.py:375-379) x 128 channels is DMA'd into LDS once per 128-channel chunk and every tap's A fragments are
+// read from it; only the weights stream (3-stage LDS-DMA ring, counted vmcnt + raw s_barrier as gemm_bf16_glds_kernel).
+// 8 waves: wave (wm, wn) owns output rows py = 4*wm..+4 of the patch (16 pixels each = one A fragment) x 64 output channels.
+// LDS: halo [HD*HD pixels][128 ch] bf16, chunk c (16 B) of pixel h at slot c ^ (h & 15); weight stage [128 n][64 k], chunk c of
+// row r at slot c ^ (r & 7).  Requirements: Cin % 128 == 0, Cout % 128 == 0 handled by the n grid, Ho % 16 == 0, Wo % 16 == 0.
+#define CH_HALO_MAX (18 * 18)
+template <int UPS>
+__global__ __launch_bounds__(512) void conv3_halo_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem3[];
+    constexpr int HD = (16 >> UPS) + 2, HP = HD * HD;
+    bf16_t* halo = smem3;                                   // [CH_HALO_MAX][128]
+    bf16_t* wst = smem3 + CH_HALO_MAX * 128;                // 3 x [128][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * BN, tile = blockIdx.y;
+    const int tw = p.Wo >> 4, th = p.Ho >> 4;
+    const int b = tile / (tw * th), t2 = tile - b * (tw * th), ty = t2 / tw, tx = t2 - ty * tw;
+    const int Hin = p.Ho >> UPS, Win = p.Wo >> UPS;
+    const int hy0 = ((16 * ty - 1) >> UPS), hx0 = ((16 * tx - 1) >> UPS);      // arithmetic shift: -1 >> 1 == -1
+    const bf16_t* A = (const bf16_t*)p.A + (long)b * Hin * Win * p.Cin;
+    const bf16_t* W = (const bf16_t*)p.W;
+    const bf16_t* zero = (const bf16_t*)p.zero;
+    const int fr = lane & 15, fq = lane >> 4;
+    // weight loader: wave w, pass i covers rows i*64 + w*8 .. +8 of the 128 n rows
+    const int lr = lane >> 3, gchunk = ((lane & 7) ^ lr) * 8;
+    const bf16_t* wrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int r = i * 64 + wave * 8 + lr; wrow[i] = (n0 + r) < p.N ? W + (long)(n0 + r) * p.ldw + gchunk : nullptr; }
+    auto issue_w = [&](int buf, int kglob) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* src = wrow[i] ? wrow[i] + kglob : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(wst + buf * (BN * G2_BK) + (i * 64 + wave * 8) * G2_BK), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nchunk = p.Cin >> 7;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        // ---- halo of this 128-channel chunk: one wave instruction = 4 pixels x 256 B
+        __syncthreads();                                   // everyone is done with the previous chunk's halo and weight stages
+        for (int q = wave; q * 4 < HP; q += 8) {
+            const int pix = q * 4 + (lane >> 4), slot = lane & 15;
+            const int hy = pix / HD, hx = pix - hy * HD, iy = hy0 + hy, ix = hx0 + hx;
+            const bf16_t* src = zero;
+            if (pix < HP && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) src = A + ((long)iy * Win + ix) * p.Cin + ch * 128 + ((slot ^ (pix & 15)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(halo + q * 4 * 128), 16, 0, 0);
+        }
+        // weight ring for this chunk: k-steps s = tap*2 + c64 (18 of them); global k = tap*Cin + ch*128 + c64*64
+        auto kglob = [&](int s_) { return (s_ >> 1) * p.Cin + ch * 128 + (s_ & 1) * 64; };
+        issue_w(0, kglob(0)); issue_w(1, kglob(1));
+        int buf = 0;
+        for (int s_ = 0; s_ < 18; ++s_) {
+            // weights of step s_ landed (2 pieces per wave per stage; the next stage may stay in flight); at s_ == 0 this also covers the halo
+            if (s_ == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (s_ + 1 < 18) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s_ + 2 < 18) issue_w(buf >= 1 ? buf - 1 : 2, kglob(s_ + 2));
+            const int tap = s_ >> 1, c64 = s_ & 1, dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const bf16_t* ws = wst + buf * (BN * G2_BK);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 a[4], bb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int h = (((16 * ty + wm * 4 + i + dy) >> UPS) - hy0) * HD + (((16 * tx + fr + dx) >> UPS) - hx0);
+                    a[i] = *(const bf16x8*)(halo + h * 128 + (((c64 * 8 + kk * 4 + fq) ^ (h & 15)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int r = wn * 64 + j * 16 + fr; bb[j] = *(const bf16x8*)(ws + r * G2_BK + (((kk * 4 + fq) ^ (r & 7)) << 3)); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+            buf = buf + 1 == 3 ? 0 : buf + 1;
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: out = rnd(rnd(acc + bias) + R), 16-byte loads/stores: lane = (pixel rr of the patch row, 8 consecutive channels)
+    const bf16_t* bias = (const bf16_t*)p.bias; const bf16_t* R = (const bf16_t*)p.R;
+    float* strip = (float*)smem3 + wave * (16 * 68);
+    const int ec = (lane & 7) * 8, en = n0 + wn * 64 + ec;
+    float bv[8];
+    {
+        const uint4 u = bias ? *(const uint4*)(bias + en) : make_uint4(0, 0, 0, 0);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bv[2 * e] = __uint_as_float(w[e] << 16); bv[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 q = acc[i][j];
+            float* d = strip + ((lane >> 4) * 4) * 68 + j * 16 + fr;
+            d[0] = q[0]; d[68] = q[1]; d[136] = q[2]; d[204] = q[3];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int oy = 16 * ty + wm * 4 + i;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int rr = pass * 8 + (lane >> 3);
+            const long mr = ((long)b * p.Ho + oy) * p.Wo + 16 * tx + rr;
+            const float4 s0 = *(const float4*)(strip + rr * 68 + ec), s1 = *(const float4*)(strip + rr * 68 + ec + 4);
+            float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e] + bv[e]));
+            if (R) {
+                const uint4 u = *(const uint4*)(R + mr * p.ldr + en);
+                const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] = v[2 * e] + __uint_as_float(w[e] << 16); v[2 * e + 1] = v[2 * e + 1] + __uint_as_float(w[e] & 0xffff0000u); }
+            }
+            uint4 o;
+            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+            *(uint4*)((bf16_t*)p.C + mr * p.ldc + en) = o;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -181,7 +460,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     const long zC = z0 * p.sC0 + z1 * p.sC1, zR = z0 * p.sR0 + z1 * p.sR1;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int lrow = tid >> 2, lkc = (tid & 3) * 4;
-    const Geo geo = { p.M, p.Cin, p.Ho, p.Wo, p.ups, p.lda };
+    const Geo geo = { p.M, p.Cin, p.Ho, p.Wo, p.ups, p.lda, p.patch };
     const ARow ar = make_arow<AMODE>(geo, m0 + lrow);
     const bool wok = (n0 + lrow) < p.N;
     const float* wp = W + (long)(n0 + lrow) * p.ldw + lkc;
@@ -224,7 +503,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
             if (m < p.M && n < p.N)
-                ((float*)p.C)[zC + (long)m * p.ldc + n] = epi_value<float>(p, bias, scale, R, zR, m, n, acc[i][j]);
+                ((float*)p.C)[zC + (long)m * p.ldc + n] = epi_value<float>(p, bias, scale, R, zR, m, (long)m, n, acc[i][j]);
         }
 }
 
@@ -234,11 +513,56 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
     if (p.nb0 <= 0) p.nb0 = 1;
     if (p.nb1 <= 0) p.nb1 = 1;
     if (mode == 1) {
+        if (amode != AMODE_CONV3 || (p.Ho & 15) || (p.Wo & 15) || getenv("CAR_CONV_LINEAR")) p.patch = 0;
         dim3 g((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nb0 * p.nb1);
+        // LDS-DMA kernel for the big GEMMs (>= 1 tile of 256 rows per CU) whenever every 16-byte chunk it fetches is aligned and whole
+        static void* zero_page[16] = {};
+        static bool attr_set = false;
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 16 && !zero_page[dev]) { if (hipMalloc(&zero_page[dev], 256) == hipSuccess) (void)hipMemset(zero_page[dev], 0, 256); else zero_page[dev] = nullptr; }
+        // 3x3 conv with the input halo resident in LDS (conv3_halo_kernel): stride 1, optional folded x2 upsample
+        if (amode == AMODE_CONV3 && dev >= 0 && dev < 16 && zero_page[dev] && p.Cin % 128 == 0 && (p.Ho & 15) == 0 && (p.Wo & 15) == 0 && (p.ups == 0 || p.ups == 1) &&
+            p.K == 9 * p.Cin && p.ldw % 8 == 0 && (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.W % 16 == 0 && !p.swiglu && !p.out_f32 && p.act == ACT_NONE &&
+            p.nb0 * p.nb1 == 1 && p.alpha == 1.0f && p.N % 128 == 0 && !p.scale && p.bias_mode != BIAS_M && p.ldc % 8 == 0 && (!p.R || p.ldr % 8 == 0) &&
+            !getenv("CAR_GEMM_V1") && !getenv("CAR_NO_HALO")) {
+            static bool attr3 = false;
+            const size_t sh3 = (size_t)(CH_HALO_MAX * 128 + 3 * BN * G2_BK) * 2;
+            if (!attr3) {
+                (void)hipFuncSetAttribute((const void*)conv3_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3);
+                (void)hipFuncSetAttribute((const void*)conv3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3);
+                attr3 = true;
+            }
+            p.zero = zero_page[dev];
+            const dim3 g3((p.N + BN - 1) / BN, (unsigned)((long)p.M / 256));
+            if (p.ups == 0) hipLaunchKernelGGL(conv3_halo_kernel<0>, g3, dim3(512), sh3, st, p);
+            else hipLaunchKernelGGL(conv3_halo_kernel<1>, g3, dim3(512), sh3, st, p);
+            return;
+        }
+        const bool al16 = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && p.ldw % 8 == 0 && p.sW0 % 8 == 0 && p.sW1 % 8 == 0 && p.sA0 % 8 == 0 && p.sA1 % 8 == 0;
+        const long tiles = (long)((p.N + BN - 1) / BN) * ((p.M + G2_BM - 1) / G2_BM) * p.nb0 * p.nb1;
+        const bool ok2 = dev >= 0 && dev < 16 && p.K % G2_BK == 0 && al16 && tiles >= 256 && !getenv("CAR_GEMM_V1") &&
+                         (amode == AMODE_PLAIN ? p.lda % 8 == 0 : (amode == AMODE_CONV3 && p.Cin % G2_BK == 0));
+        if (ok2) {
+            const size_t sh = (size_t)G2_NS * G2_STAGE * 2;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AMODE_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AMODE_CONV3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+                attr_set = true;
+            }
+            if (!zero_page[dev]) { if (hipMalloc(&zero_page[dev], 256) == hipSuccess) (void)hipMemset(zero_page[dev], 0, 256); else zero_page[dev] = nullptr; }
+            if (zero_page[dev]) {
+                p.zero = zero_page[dev];
+                dim3 g2((p.N + BN - 1) / BN, (p.M + G2_BM - 1) / G2_BM, p.nb0 * p.nb1);
+                if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_bf16_glds_kernel<AMODE_PLAIN>, g2, dim3(512), sh, st, p);
+                else hipLaunchKernelGGL(gemm_bf16_glds_kernel<AMODE_CONV3>, g2, dim3(512), sh, st, p);
+                return;
+            }
+        }
         if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);
         else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_CONV3>, g, dim3(256), 0, st, p);
     } else {
+        p.patch = 0;                              // the exact-mode kernel enumerates pixels linearly
         dim3 g((p.N + 63) / 64, (p.M + 63) / 64, p.nb0 * p.nb1);
         if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_f32_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);
         else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_f32_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);
