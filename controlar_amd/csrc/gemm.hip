@@ -9,7 +9,7 @@
 #include "car_common.h"
 
 template <typename T>
-__device__ inline float epi_value(const GemmP& p, const T* bias, const T* scale, const T* R, long zR, int m, long mrow, int n, float v) {
+__device__ __forceinline__ float epi_value(const GemmP& p, const T* bias, const T* scale, const T* R, long zR, int m, long mrow, int n, float v) {
     v *= p.alpha;
     if (p.bias_mode == BIAS_N) v += ET<T>::ld(bias + n);
     else if (p.bias_mode == BIAS_M) v += ET<T>::ld(bias + m);
@@ -33,7 +33,7 @@ __device__ inline void patch_decode(int Ho, int Wo, int m, int& b, int& y, int& 
     y = ty * 16 + (within >> 4); x = tx * 16 + (within & 15);
 }
 // row of C / R that GEMM row m addresses (the NHWC pixel index under patch order, m itself otherwise)
-__device__ inline long out_row(const GemmP& p, int m) {
+__device__ __forceinline__ long out_row(const GemmP& p, int m) {
     if (!p.patch) return m;
     int b, y, x; patch_decode(p.Ho, p.Wo, m, b, y, x);
     return ((long)b * p.Ho + y) * p.Wo + x;
@@ -67,6 +67,98 @@ __device__ inline long a_off(const Geo p, const ARow r, int k) {
     const int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
     if (yy < 0 || yy >= p.Ho || xx < 0 || xx >= p.Wo) return -1;
     return (r.base + (long)(yy >> p.ups) * (p.Wo >> p.ups) + (xx >> p.ups)) * p.Cin + c;
+}
+
+// ---- one 16 x 64 fp32 strip (ld 68) of a wave's accumulators -> C, through the epilogue.  Vector form: a lane owns 8 consecutive
+// columns of one row (16-byte bias / scale / residual loads, one 16-byte bf16 store or two float4 stores) whenever the row
+// strides and N allow it; the element-wise form (lane = column) remains for ragged shapes (e.g. the 1025-wide score matrices).
+__device__ __forceinline__ void ld8bf(const bf16_t* p, float (&v)[8]) {
+    const uint4 u = *(const uint4*)p; const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+enum { EP_VEC = 0, EP_SCALAR = 1, EP_SWIGLU = 2 };
+__device__ __forceinline__ int strip_path(const GemmP& p, long zC, long zR) {
+    if (p.swiglu) return EP_SWIGLU;
+    const bool vec = (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0) && p.bias_mode != BIAS_M &&
+                     ((zC | zR) & 7) == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.R || ((uintptr_t)p.R & 15) == 0);
+    return vec ? EP_VEC : EP_SCALAR;
+}
+template <int PATH>
+__device__ __forceinline__ void store_strip(const GemmP& p, const float* strip, int mb, int nb, long zC, long zR, int lane) {
+    const bf16_t* bias = (const bf16_t*)p.bias; const bf16_t* scale = (const bf16_t*)p.scale; const bf16_t* R = (const bf16_t*)p.R;
+    if (PATH == EP_SWIGLU) {
+        // column blocks of 16 alternate w1 | w3 (packed at load time): out[m, n/2] = silu(a) * c ; lane = (row, 8 of the 32 outputs)
+        const int rr = lane >> 2, c = (lane & 3) * 8, src = (c >> 4) * 32 + (c & 15), m = mb + rr;
+        if (m < p.M && nb + src + 24 <= p.N && (p.ldc & 7) == 0 && (zC & 7) == 0) {
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float a0 = bf2f(f2bf(strip[rr * 68 + src + e])), c0 = bf2f(f2bf(strip[rr * 68 + src + 16 + e]));
+                const float a1 = bf2f(f2bf(strip[rr * 68 + src + e + 1])), c1 = bf2f(f2bf(strip[rr * 68 + src + 17 + e]));
+                o[e >> 1] = (unsigned)f2bf(bf2f(f2bf(silu_f(a0))) * c0) | ((unsigned)f2bf(bf2f(f2bf(silu_f(a1))) * c1) << 16);
+            }
+            *(uint4*)((bf16_t*)p.C + zC + out_row(p, m) * p.ldc + (nb >> 1) + c) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else if (m < p.M) {
+            for (int e = 0; e < 8; ++e) {
+                const int n = nb + src + e;
+                if (n + 16 < p.N) {
+                    const float a1 = bf2f(f2bf(strip[rr * 68 + src + e])), c3 = bf2f(f2bf(strip[rr * 68 + src + 16 + e]));
+                    ((bf16_t*)p.C)[zC + out_row(p, m) * p.ldc + (nb >> 1) + c + e] = f2bf(bf2f(f2bf(silu_f(a1))) * c3);
+                }
+            }
+        }
+        return;
+    }
+    if (PATH == EP_VEC) {
+        const int ec = (lane & 7) * 8, n = nb + ec;
+        float bv[8], sv[8];
+        if (n < p.N) {
+            if (p.bias_mode == BIAS_N) ld8bf(bias + n, bv);
+            if (scale) ld8bf(scale + n, sv);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int rr = pass * 8 + (lane >> 3), m = mb + rr;
+            if (m < p.M && n < p.N) {
+                const long mr = out_row(p, m);
+                const float4 s0 = *(const float4*)(strip + rr * 68 + ec), s1 = *(const float4*)(strip + rr * 68 + ec + 4);
+                float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, rv8[8];
+                if (R) ld8bf(R + zR + mr * p.ldr + n, rv8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = v[e] * p.alpha;
+                    if (p.bias_mode == BIAS_N) x += bv[e];
+                    x = bf2f(f2bf(x));
+                    if (p.act == ACT_GELU_ERF) x = bf2f(f2bf(gelu_erf_f(x)));
+                    else if (p.act == ACT_GELU_TANH) x = bf2f(f2bf(gelu_tanh_f(x)));
+                    else if (p.act == ACT_SILU) x = bf2f(f2bf(silu_f(x)));
+                    if (scale) x = bf2f(f2bf(x * sv[e]));
+                    if (R) x = bf2f(f2bf(x + rv8[e]));
+                    v[e] = x;
+                }
+                if (p.out_f32) {
+                    float* d = (float*)p.C + zC + mr * p.ldc + n;
+                    *(float4*)d = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    uint4 o;
+                    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                    *(uint4*)((bf16_t*)p.C + zC + mr * p.ldc + n) = o;
+                }
+            }
+        }
+        return;
+    }
+    for (int rr = 0; rr < 16; ++rr) {
+        const int m = mb + rr, n = nb + lane;
+        if (m < p.M && n < p.N) {
+            const long mr = out_row(p, m);
+            const float v = epi_value<bf16_t>(p, bias, scale, R, zR, m, mr, n, strip[rr * 68 + lane]);
+            if (p.out_f32) ((float*)p.C)[zC + mr * p.ldc + n] = v;
+            else ((bf16_t*)p.C)[zC + mr * p.ldc + n] = f2bf(v);
+        }
+    }
 }
 
 // =========================================================================== bf16 MFMA
@@ -144,43 +236,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 
     // ---- epilogue: each wave stages 16x64 fp32 strips of its accumulators through LDS so that the
     // (large) per-element epilogue runs in a rolled loop and global stores are row-contiguous.
-    const bf16_t* bias = (const bf16_t*)p.bias; const bf16_t* scale = (const bf16_t*)p.scale; const bf16_t* R = (const bf16_t*)p.R;
     float* strip = (float*)smem + wave * (16 * 68);
-    const int swiglu = p.swiglu, out_f32 = p.out_f32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 q = acc[i][j];
-            float* d = strip + ((lane >> 4) * 4) * 68 + j * 16 + fr;
-            d[0] = q[0]; d[68] = q[1]; d[136] = q[2]; d[204] = q[3];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int mb = m0 + wm * 64 + i * 16, nb = n0 + wn * 64;
-        if (swiglu) {
-            // column blocks of 16 alternate w1 | w3 (packed at load time): out[m, n/2] = silu(a) * c
-            const int c = lane & 31, src = (c >> 4) * 32 + (c & 15);
-            for (int rr = (lane >> 5); rr < 16; rr += 2) {
-                const int m = mb + rr, n = nb + src;
-                if (m < p.M && n < p.N) {
-                    const float a1 = bf2f(f2bf(strip[rr * 68 + src])), c3 = bf2f(f2bf(strip[rr * 68 + src + 16]));
-                    const float sl = bf2f(f2bf(silu_f(a1)));
-                    ((bf16_t*)p.C)[zC + out_row(p, m) * p.ldc + (nb >> 1) + c] = f2bf(sl * c3);
-                }
-            }
-        } else {
-            for (int rr = 0; rr < 16; ++rr) {
-                const int m = mb + rr, n = nb + lane;
-                if (m < p.M && n < p.N) {
-                    const long mr = out_row(p, m);
-                    const float v = epi_value<bf16_t>(p, bias, scale, R, zR, m, mr, n, strip[rr * 68 + lane]);
-                    if (out_f32) ((float*)p.C)[zC + mr * p.ldc + n] = v;
-                    else ((bf16_t*)p.C)[zC + mr * p.ldc + n] = f2bf(v);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+    const int path = strip_path(p, zC, zR);       // chosen once: each path's strip loop stays small enough to unroll (acc stays in registers)
+#define STRIP_LOOP(PATH)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            const f32x4 q = acc[i][j];                                                            \
+            float* d = strip + ((lane >> 4) * 4) * 68 + j * 16 + fr;                              \
+            d[0] = q[0]; d[68] = q[1]; d[136] = q[2]; d[204] = q[3];                              \
+        }                                                                                         \
+        __builtin_amdgcn_wave_barrier();                                                          \
+        store_strip<PATH>(p, strip, m0 + wm * 64 + i * 16, n0 + wn * 64, zC, zR, lane);           \
+        __builtin_amdgcn_wave_barrier();                                                          \
     }
+    if (path == EP_VEC) { STRIP_LOOP(EP_VEC) } else if (path == EP_SWIGLU) { STRIP_LOOP(EP_SWIGLU) } else { STRIP_LOOP(EP_SCALAR) }
+#undef STRIP_LOOP
 }
 
 // =========================================================================== bf16 MFMA, LDS-DMA staged (large-M GEMMs / convs)
@@ -277,42 +347,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmP p) {
     __syncthreads();                              // the epilogue strips reuse the stage memory
 
     // ---- epilogue (same as gemm_bf16_kernel): 16x64 fp32 strips through LDS, rolled per-element epilogue, row-contiguous stores
-    const bf16_t* bias = (const bf16_t*)p.bias; const bf16_t* scale = (const bf16_t*)p.scale; const bf16_t* R = (const bf16_t*)p.R;
     float* strip = (float*)smem2 + wave * (16 * 68);
-    const int swiglu = p.swiglu, out_f32 = p.out_f32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 q = acc[i][j];
-            float* d = strip + ((lane >> 4) * 4) * 68 + j * 16 + fr;
-            d[0] = q[0]; d[68] = q[1]; d[136] = q[2]; d[204] = q[3];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int mb = m0 + wm * 64 + i * 16, nb = n0 + wn * 64;
-        if (swiglu) {
-            const int c = lane & 31, src = (c >> 4) * 32 + (c & 15);
-            for (int rr = (lane >> 5); rr < 16; rr += 2) {
-                const int m = mb + rr, n = nb + src;
-                if (m < p.M && n < p.N) {
-                    const float a1 = bf2f(f2bf(strip[rr * 68 + src])), c3 = bf2f(f2bf(strip[rr * 68 + src + 16]));
-                    const float sl = bf2f(f2bf(silu_f(a1)));
-                    ((bf16_t*)p.C)[zC + out_row(p, m) * p.ldc + (nb >> 1) + c] = f2bf(sl * c3);
-                }
-            }
-        } else {
-            for (int rr = 0; rr < 16; ++rr) {
-                const int m = mb + rr, n = nb + lane;
-                if (m < p.M && n < p.N) {
-                    const long mr = out_row(p, m);
-                    const float v = epi_value<bf16_t>(p, bias, scale, R, zR, m, mr, n, strip[rr * 68 + lane]);
-                    if (out_f32) ((float*)p.C)[zC + mr * p.ldc + n] = v;
-                    else ((bf16_t*)p.C)[zC + mr * p.ldc + n] = f2bf(v);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+    const int path = strip_path(p, zC, zR);       // chosen once: each path's strip loop stays small enough to unroll (acc stays in registers)
+#define STRIP_LOOP(PATH)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            const f32x4 q = acc[i][j];                                                            \
+            float* d = strip + ((lane >> 4) * 4) * 68 + j * 16 + fr;                              \
+            d[0] = q[0]; d[68] = q[1]; d[136] = q[2]; d[204] = q[3];                              \
+        }                                                                                         \
+        __builtin_amdgcn_wave_barrier();                                                          \
+        store_strip<PATH>(p, strip, m0 + wm * 64 + i * 16, n0 + wn * 64, zC, zR, lane);           \
+        __builtin_amdgcn_wave_barrier();                                                          \
     }
+    if (path == EP_VEC) { STRIP_LOOP(EP_VEC) } else if (path == EP_SWIGLU) { STRIP_LOOP(EP_SWIGLU) } else { STRIP_LOOP(EP_SCALAR) }
+#undef STRIP_LOOP
 }
 
 // =========================================================================== 3x3 conv with an LDS-resident halo (VQ decoder)
@@ -540,7 +589,7 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
         }
         const bool al16 = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && p.ldw % 8 == 0 && p.sW0 % 8 == 0 && p.sW1 % 8 == 0 && p.sA0 % 8 == 0 && p.sA1 % 8 == 0;
         const long tiles = (long)((p.N + BN - 1) / BN) * ((p.M + G2_BM - 1) / G2_BM) * p.nb0 * p.nb1;
-        const bool ok2 = dev >= 0 && dev < 16 && p.K % G2_BK == 0 && al16 && tiles >= 256 && !getenv("CAR_GEMM_V1") &&
+        const bool ok2 = dev >= 0 && dev < 16 && p.K % G2_BK == 0 && p.K >= 512 && al16 && tiles >= 512 && !getenv("CAR_GEMM_V1") &&
                          (amode == AMODE_PLAIN ? p.lda % 8 == 0 : (amode == AMODE_CONV3 && p.Cin % G2_BK == 0));
         if (ok2) {
             const size_t sh = (size_t)G2_NS * G2_STAGE * 2;
