@@ -352,6 +352,25 @@ def case_vq_encode(name, cfg, H, W, seed=2):
     print(name, idx.shape, "distinct", len(np.unique(idx.numpy())))
 
 
+def case_sampler(name="sampler_v16384"):
+    """The reference's own sample() internals (generate.py:17-74) at its real defaults: V = 16384, top_k = 2000 (sample_t2i.py:209),
+    with and without nucleus filtering and a temperature.  Pins the oracle's top_k_top_p_filtering and gives the GPU sampler
+    (ops.hip sample_stochastic_kernel) its target distribution."""
+    g = torch.Generator().manual_seed(5)
+    row = (torch.randn(1, 16384, generator=g) * 3.0).float()
+    out = {"logits": row.numpy()[0].copy()}
+    settings = [(2000, 1.0, 1.0), (2000, 0.9, 1.0), (0, 0.9, 0.7), (50, 1.0, 1.3)]
+    out["settings"] = np.array(settings, dtype=np.float64)
+    for i, (k, p, t) in enumerate(settings):
+        x = row.clone()[:, None, :]                                   # sample() takes [B, T, V] and uses the last position
+        idx, probs = ref_gen.sample(x, temperature=t, top_k=int(k), top_p=p, sample_logits=False)
+        out[f"probs_{i}"] = probs.numpy()[0].astype(np.float32)
+        out[f"greedy_{i}"] = np.int64(idx.item())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, [int((out[f"probs_{i}"] > 0).sum()) for i in range(len(settings))])
+
+
+CASES["sampler_v16384"] = case_sampler
 CASES["vq_encode_tiny"] = lambda: case_vq_encode("vq_encode_tiny", C.tiny_t2i().vq, 128, 128)
 CASES["vq_encode_vq16_64x64"] = lambda: case_vq_encode("vq_encode_vq16_64x64", C.VQConfig(), 64, 64)
 

@@ -96,6 +96,10 @@ def test_header_is_valid_c99_and_example_compiles():
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "examples", "c_abi_example.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    if os.path.isdir("/opt/rocm/include"):       # the runnable client (tests/test_c_example_gpu.py links and runs it on the GPU box)
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "examples", "c_abi_run.c")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
 
 
 def test_decode_weight_fragment_packing_layout():

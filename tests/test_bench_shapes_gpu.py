@@ -130,3 +130,51 @@ def test_graph_cache_distinguishes_n_new():
     assert cs["B"] >= 2
     assert torch.equal(got64, want64) and torch.equal(got60, want60)
     assert torch.equal(got60, want64[:, :60])
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_stochastic_sampler_at_the_reference_defaults(i):
+    """sample() with sample_logits=True at V = 16384, top_k = 2000 (sample_t2i.py:209) and three more settings: 1M draws of the
+    on-device sampler against the distribution the reference's own sample() produced (tests/golden/sampler_v16384.npz):
+    nothing outside the reference's support, total-variation distance < 0.05."""
+    from controlar_amd import config as C
+    from controlar_amd.engine import Engine
+    gold = np.load(os.path.join(GOLDEN, "sampler_v16384.npz"))
+    k, p, t = [float(x) for x in gold["settings"][i]]
+    want = torch.from_numpy(gold[f"probs_{i}"]).double()
+    eng = Engine(C.tiny_t2i(64, "canny"), "bf16")
+    rows, reps, V = 8192, 128, 16384
+    lg = torch.from_numpy(gold["logits"])[None].repeat(rows, 1).cuda()
+    counts = torch.zeros(V, dtype=torch.float64)
+    for s in range(reps):
+        toks = eng.sample(lg, temperature=t, top_k=int(k), top_p=p, sample_logits=True, seed=1234, step=s).cpu().long()
+        counts += torch.bincount(toks, minlength=V).double()
+    emp = counts / counts.sum()
+    assert float(emp[want == 0].sum()) == 0.0, f"{int((emp[want == 0] > 0).sum())} tokens drawn outside the reference's support"
+    tv = 0.5 * float((emp - want).abs().sum())
+    assert tv < 0.05, tv
+    g = eng.sample(lg[:4], temperature=t, top_k=int(k), top_p=p, sample_logits=False).cpu()
+    assert bool((g == int(gold[f"greedy_{i}"])).all())
+    eng.close()
+
+
+def test_cfg_interval_with_stochastic_sampling():
+    """cfg_interval (generate.py:121-122) under sample_logits=True: reproducible for a seed, different across seeds, and after the
+    interval the logits handed to sample() are the conditional half alone."""
+    from tests.cases import load_case
+    from controlar_amd.engine import Engine
+    cs = load_case("tiny_cfg_interval")
+    eng = Engine(cs["cfg"], "fp32"); eng.load_state_dict(cs["gsd"]); eng.finalize()
+    eng.encode_control(cs["img"].cuda())
+    kw = dict(cfg_scale=cs["cfg_scale"], cfg_interval=cs["cfg_interval"], temperature=1.0, top_k=50, top_p=0.95, sample_logits=True)
+    a = eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), seed=7, **kw).cpu()
+    b = eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), seed=7, **kw).cpu()
+    c = eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), seed=8, **kw).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    _, mixed = eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), forced_tokens=a, return_logits=True, seed=7, **kw)
+    _, cond = eng.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), forced_tokens=a, return_logits=True, seed=7,
+                           **dict(kw, cfg_scale=1.0))
+    first_plain = cs["cfg_interval"] + 2                 # loop index step-1 > cfg_interval  <=>  step >= cfg_interval + 2
+    torch.testing.assert_close(mixed[:, first_plain:].cpu(), cond[:, first_plain:].cpu(), atol=2e-4, rtol=1e-4)
+    assert float((mixed[:, 1:first_plain] - cond[:, 1:first_plain]).abs().max()) > 1e-2      # before it the CFG mix is in effect
+    eng.close()

@@ -128,3 +128,18 @@ def test_oracle_vq_encode_matches_reference(name, mk, hw, golden_dir):
     img = synth.smooth_control(2, hw, hw, seed=77) + 0.1 * synth.canny_like_control(2, hw, hw, seed=78)
     idx, _ = O.vq_encode(sd, cfg, img)
     assert np.array_equal(idx.numpy(), gold["tokens"])
+
+
+def test_sampler_filter_pinned_by_the_reference_at_its_defaults(golden_dir):
+    """generate.py:17-74 at V = 16384, top_k = 2000 (the reference's real defaults, sample_t2i.py:209) and three more settings:
+    the oracle's filtered softmax must equal the distribution the reference's own sample() produced (tests/golden/make_golden.py
+    case_sampler), support for support."""
+    gold = np.load(os.path.join(golden_dir, "sampler_v16384.npz"))
+    row = torch.from_numpy(gold["logits"])[None]
+    for i, (k, p, t) in enumerate(gold["settings"]):
+        lg = row.clone() / max(float(t), 1e-5)
+        probs = torch.softmax(O.top_k_top_p_filtering(lg, int(k), float(p)), dim=-1)[0].numpy()
+        want = gold[f"probs_{i}"]
+        assert np.array_equal(probs > 0, want > 0), (i, int((probs > 0).sum()), int((want > 0).sum()))
+        np.testing.assert_allclose(probs, want, rtol=1e-6, atol=1e-9)
+        assert int(O.sample(row.clone(), temperature=float(t), top_k=int(k), top_p=float(p), sample_logits=False).item()) == int(gold[f"greedy_{i}"])
