@@ -63,6 +63,7 @@ SYMBOLS = {
     "car_generate_c2i": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CarSampling), C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "car_sample_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(CarSampling), C.c_int32, C.c_void_p, C.c_void_p]),
+    "car_canny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "car_vq_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "car_vq_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "car_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CarStats)]),

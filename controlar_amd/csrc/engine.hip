@@ -63,6 +63,10 @@ void car_launch_mask_first_valid(const unsigned char* mask, int* jmin, int b, in
 void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, hipStream_t st);
 void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st);
 void car_launch_build_mask(const int64_t* emb_mask, const int* row_img, unsigned char* out, int b, int T, hipStream_t st);
+// canny.hip
+void car_launch_canny_grad_nms(const unsigned char* img, unsigned char* map, int B, int H, int W, int low, int high, hipStream_t st);
+void car_launch_canny_hyst(unsigned char* map, int B, int H, int W, int* changed, hipStream_t st);
+void car_launch_canny_finish(int mode, const unsigned char* map, unsigned char* edges, void* control, int B, long HW, hipStream_t st);
 // pack.hip
 void car_launch_rows_to_bf16(const void* src, int dtype, void* dst, long N, long K, int ileave, hipStream_t st);
 void car_launch_pack_frag_bf16(const void* src, void* dst, long N, long K, hipStream_t st);
@@ -141,6 +145,7 @@ struct car_ctx {
     SampleDyn h_dyn = {};
     int dbg_skip = 0;
     DevBuf rowimg;       // [b] int: image index of each row
+    DevBuf canny_map;    // car_canny: uint8 [B,H,W] candidate/edge map + the "changed" flag
     int st_b = 0, st_T = 0, st_nsteps = 0, st_has_mask = 0; double st_wbytes = 0; const int* st_jmin = nullptr;   // inputs of the lazy decode_algo_bytes
     // decode graph
     hipGraphExec_t gexec = nullptr; std::string gkey;
@@ -228,7 +233,7 @@ extern "C" void car_destroy(car_ctx* c) {
     for (auto& kv : c->resize_cache) { (void)hipFree(kv.second.iy); (void)hipFree(kv.second.ix); if (kv.second.wy) (void)hipFree(kv.second.wy); if (kv.second.wx) (void)hipFree(kv.second.wx); }
     if (c->rope) (void)hipFree(c->rope);
     c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
-    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release();
+    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release(); c->canny_map.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
     (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 7; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); }
@@ -1347,6 +1352,37 @@ extern "C" int car_debug_control_tokens(car_ctx* c, int32_t k, float* host_out, 
     if (!n) FAIL(c, "no control tokens cached");
     if (c->mode == CAR_F32) { HIPCHK(c, hipMemcpy(host_out, c->ctrl[k].p, n * 4, hipMemcpyDeviceToHost)); }
     else { std::vector<bf16_t> hb(n); HIPCHK(c, hipMemcpy(hb.data(), c->ctrl[k].p, n * 2, hipMemcpyDeviceToHost)); for (size_t i = 0; i < n; ++i) host_out[i] = bf2f(hb[i]); }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- Canny control extraction
+// cv2.Canny(img, low, high) of condition/canny.py:6-14 for a batch of 8-bit RGB photos [B,H,W,3] (device).  edges_out: uint8 [B,H,W] in
+// {0,255} or NULL; control_out: [B,3,H,W] in the context's element type = 2*(edges/255 - 0.5) replicated over 3 channels
+// (sample_t2i.py:125,141) or NULL — ready for car_encode_control.  The hysteresis fixed point is checked on the host between launches
+// (this runs in front of the path, not inside the token loop).
+extern "C" int car_canny(car_ctx* c, const uint8_t* img_hwc, int32_t B, int32_t H, int32_t W, float low_threshold, float high_threshold,
+                         uint8_t* edges_out, void* control_out, void* stream_) {
+    if (!c) return -1;
+    if (!img_hwc || B <= 0 || H <= 0 || W <= 0 || (!edges_out && !control_out)) FAIL(c, "car_canny: bad arguments");
+    if (low_threshold > high_threshold) { const float t = low_threshold; low_threshold = high_threshold; high_threshold = t; }
+    hipStream_t caller = (hipStream_t)stream_, st = c->stream;
+    const long HW = (long)H * W;
+    const size_t map_bytes = ((size_t)B * HW + 3) & ~(size_t)3;
+    NEED(c, c->canny_map, map_bytes + 16);
+    unsigned char* map = (unsigned char*)c->canny_map.p; int* changed = (int*)(map + map_bytes);
+    fence_in(c, caller);
+    car_launch_canny_grad_nms(img_hwc, map, B, H, W, (int)std::floor(low_threshold), (int)std::floor(high_threshold), st);
+    for (int it = 0; it < 100000; ++it) {
+        int h = 0;
+        HIPCHK(c, hipMemsetAsync(changed, 0, 4, st));
+        car_launch_canny_hyst(map, B, H, W, changed, st);
+        HIPCHK(c, hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (!h) break;
+    }
+    car_launch_canny_finish(c->mode, map, edges_out, control_out, B, HW, st);
+    fence_out(c, caller);
+    HIPCHK(c, hipGetLastError());
     return 0;
 }
 

@@ -197,6 +197,21 @@ class Engine:
                     "car_vq_encode")
         return out
 
+    def canny(self, img: torch.Tensor, low_threshold: float = 100, high_threshold: float = 200, want_control: bool = False):
+        """cv2.Canny(img, low, high) of condition/canny.py:6-14 on the GPU.  img uint8 [B,H,W,3] (or [H,W,3]) -> uint8 [B,H,W] in
+        {0,255}; with want_control also the control tensor [B,3,H,W] = 2*(edges/255-0.5) (sample_t2i.py:125,141)."""
+        single = img.dim() == 3
+        x = (img[None] if single else img).to(device=self.device, dtype=torch.uint8).contiguous()
+        B, H, W, ch = x.shape
+        assert ch == 3, "expected an RGB image [.., H, W, 3]"
+        edges = torch.empty(B, H, W, dtype=torch.uint8, device=self.device)
+        ctrl = torch.empty(B, 3, H, W, dtype=self.dtype, device=self.device) if want_control else None
+        self._check(self.lib.car_canny(self._h, C.c_void_p(x.data_ptr()), B, H, W, float(low_threshold), float(high_threshold),
+                                       C.c_void_p(edges.data_ptr()), C.c_void_p(ctrl.data_ptr() if ctrl is not None else 0), C.c_void_p(_stream_ptr())),
+                    "car_canny")
+        edges = edges[0] if single else edges
+        return (edges, ctrl) if want_control else edges
+
     def stats(self) -> dict:
         s = L.CarStats()
         self._check(self.lib.car_get_stats(self._h, C.byref(s)), "car_get_stats")

@@ -139,6 +139,16 @@ int car_generate(car_ctx* ctx, const void* text_emb, int32_t text_dtype, const i
                  int32_t* out_tokens, const int32_t* forced_tokens, float* logits_out, void* stream);
 
 /*
+ * Canny control extraction — replaces CannyDetector.__call__ = cv2.Canny(img, low, high) (condition/canny.py:6-14; callers
+ * sample_t2i.py:123-125, sample_t2i_MR.py:139, demo 'Canny' preprocessor).  img: uint8 [B,H,W,3] (device).  edges_out: uint8 [B,H,W]
+ * in {0,255} or NULL; control_out: [B,3,H,W] in the context's element type, = 2*(edges/255 - 0.5) replicated over 3 channels
+ * (sample_t2i.py:125,141), or NULL.  Integer arithmetic of opencv-python 4.9 (Sobel 3x3, L1 magnitude, fixed-point direction test,
+ * hysteresis); works on any context (no weights needed).  Synchronises `stream` internally (hysteresis fixed point).
+ */
+int car_canny(car_ctx* ctx, const uint8_t* img_hwc, int32_t B, int32_t H, int32_t W, float low_threshold, float high_threshold,
+              uint8_t* edges_out, void* control_out, void* stream);
+
+/*
  * generate() for the class-conditional model — replaces generate.py:134-204 (c2i branch :139-154) over
  * autoregressive/models/gpt.py.  labels [B] int64 (device).  Prefix length is 1; no pad mask; control_strength
  * does not exist on this path.  NOTE: in the reference snapshot this branch only runs with cfg_scale <= 1
