@@ -4,7 +4,8 @@ hot path (control encoder -> generate -> decode_code) in libcontrolar_hip.so.
 What sits in FRONT of the path in the reference demo is injected, because it is outside this library's scope (SURVEY.md §2:
 condition extractors and the Flan-T5 encoder are upstream producers):
   * ``preprocessor(name, image, **kw) -> PIL.Image | np.ndarray`` — the reference's external ``Preprocessor`` (Canny / HED / Lineart /
-    depth).  ``'No preprocess'`` (a choice of the reference UI, demo/model.py:123-124) needs none: the image IS the control map.
+    depth).  ``'No preprocess'`` (a choice of the reference UI, demo/model.py:123-124) needs none: the image IS the control map;
+    ``'Canny'`` falls back to the built-in GPU extractor (``controlar_amd.condition.CannyDetector``) when nothing is injected.
   * ``text_encoder(prompts) -> (caption_embs [B,120,2048], emb_masks [B,120])`` — ``T5Embedder.get_text_embeddings`` (language/t5.py:58-79).
     A prompt may also be given directly as such a pair (precomputed features, as the training pipeline stores them).
 The rest — resize to 512x512, ``2*(x/255-0.5)``, left-padding of the caption, ``generate(..., sample_logits=True)``, ``decode_code``,
@@ -81,6 +82,13 @@ class Model:
     def _preprocess(self, name: str, image, **kw):
         if name == "No preprocess":
             return image
+        if self.preprocessor is None and name == "Canny":
+            # built-in: cv2.Canny on the GPU (car_canny, condition/canny.py:6-14) at the photo's own resolution; the caller resizes the map
+            # to 512x512 exactly as demo/model.py:127 does.  (The reference's external Preprocessor is not part of its repository.)
+            from .condition import CannyDetector
+            if getattr(self, "_canny", None) is None:
+                self._canny = CannyDetector(self.device)
+            return self._canny(np.array(image.convert("RGB")), kw.get("low_threshold", 100), kw.get("high_threshold", 200))
         if self.preprocessor is None:
             raise RuntimeError(f"Model: preprocessor '{name}' needs the preprocessor callable (the reference's external Preprocessor, demo/model.py:15,32); "
                                "'No preprocess' takes the image as the control map")

@@ -82,5 +82,7 @@ def test_demo_process_edge_and_depth_end_to_end():
     assert np.array_equal(np.array(a[1]), np.array(b[1])) and not np.array_equal(np.array(a[1]), np.array(c[1]))
     with pytest.raises(RuntimeError):
         m.process_edge(ctrl, "a text prompt needs the injected T5 encoder", 4.0, 1.0, 2000, 1.0, 3, 100, 200, 0.6, "No preprocess")
+    d = m.process_edge(ctrl, feats, 4.0, 1.0, 2000, 1.0, 3, 100, 200, 0.6, "Canny")     # built-in GPU Canny on the photo
+    assert len(d) == 2 and set(np.unique(np.array(d[0]))) <= {0, 255}
     with pytest.raises(RuntimeError):
-        m.process_edge(ctrl, feats, 4.0, 1.0, 2000, 1.0, 3, 100, 200, 0.6, "Canny")     # extractor not injected
+        m.process_edge(ctrl, feats, 4.0, 1.0, 2000, 1.0, 3, 100, 200, 0.6, "Hed")       # extractor not injected
