@@ -32,6 +32,14 @@ class CarConfig(C.Structure):
     ]
 
 
+class CarT5Config(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("d_model", C.c_int32), ("d_kv", C.c_int32), ("num_heads", C.c_int32), ("d_ff", C.c_int32),
+        ("num_layers", C.c_int32), ("rel_buckets", C.c_int32), ("rel_max_distance", C.c_int32), ("ln_eps", C.c_float),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
 class CarSampling(C.Structure):
     _fields_ = [
         ("cfg_scale", C.c_float), ("cfg_interval", C.c_int32), ("temperature", C.c_float), ("top_k", C.c_int32),
@@ -57,6 +65,8 @@ SYMBOLS = {
     "car_finalize_weights": (C.c_int, [C.c_void_p]),
     "car_export_packed": (C.c_int, [C.c_void_p, C.c_char_p]),
     "car_import_packed": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "car_t5_configure": (C.c_int, [C.c_void_p, C.POINTER(CarT5Config)]),
+    "car_t5_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "car_encode_control": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "car_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                C.POINTER(CarSampling), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

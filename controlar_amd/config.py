@@ -92,6 +92,35 @@ class VQConfig:
 
 
 @dataclass
+class T5Config:
+    """HF T5Config fields the encoder reads (language/t5.py:58-79 loads flan-t5-xl / t5-v1_1-xxl: feed_forward_proj 'gated-gelu')."""
+    vocab_size: int = 32128
+    d_model: int = 2048
+    d_kv: int = 64
+    num_heads: int = 32
+    d_ff: int = 5120
+    num_layers: int = 24
+    relative_attention_num_buckets: int = 32
+    relative_attention_max_distance: int = 128
+    layer_norm_epsilon: float = 1e-6
+    model_max_length: int = 120          # T5Embedder(model_max_length=120)
+
+
+def flan_t5_xl() -> T5Config:
+    """google/flan-t5-xl, the encoder every t2i sampler of the reference loads (sample_t2i.py:99-107)."""
+    return T5Config()
+
+
+def tiny_t5() -> T5Config:
+    return T5Config(vocab_size=512, d_model=64, d_kv=32, num_heads=2, d_ff=128, num_layers=2)
+
+
+def small_t5() -> T5Config:
+    """t5-small-shaped gated variant (8 heads x 64): mid-size parity case."""
+    return T5Config(vocab_size=4096, d_model=512, d_kv=64, num_heads=8, d_ff=1024, num_layers=4)
+
+
+@dataclass
 class PathConfig:
     gpt: GPTConfig = field(default_factory=GPTConfig)
     vit: ViTConfig = field(default_factory=ViTConfig)

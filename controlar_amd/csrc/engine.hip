@@ -72,6 +72,10 @@ void car_launch_rows_to_bf16(const void* src, int dtype, void* dst, long N, long
 void car_launch_pack_frag_bf16(const void* src, void* dst, long N, long K, hipStream_t st);
 void car_launch_row_amax_scale(const void* src, int dtype, float* scale, long N, long K, int ileave, hipStream_t st);
 void car_launch_quant_pack_fp8(const void* src, int dtype, const float* scale, void* rowmajor, void* pk, long N, long K, int ileave, hipStream_t st);
+void car_launch_t5_prep(const long long* ids, const long long* mask, int* ids32, unsigned char* mk, long n, int vocab, hipStream_t st);
+void car_launch_t5_softmax(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, const float* bias,
+                           const unsigned char* mask, int Tq, int n_head, hipStream_t st);
+void car_launch_t5_gated_act(int mode, const void* in, void* out, long rows, int hidden, hipStream_t st);
 void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
 void car_launch_convert(int mode, const void* src, int src_dtype, void* dst, long n, hipStream_t st);
 void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg, hipStream_t st);
@@ -146,6 +150,9 @@ struct car_ctx {
     int dbg_skip = 0;
     DevBuf rowimg;       // [b] int: image index of each row
     DevBuf canny_map;    // car_canny: uint8 [B,H,W] candidate/edge map + the "changed" flag
+    car_t5_config t5 = {}; bool has_t5 = false;
+    DevBuf t5_in;        // int32 ids [B*T] | uint8 key mask [B*T] | staging for host-side int64 inputs
+    DevBuf t5_bias; int t5_bias_T = 0;   // position bias fp32 [heads][T][T] of the last sequence length
     int st_b = 0, st_T = 0, st_nsteps = 0, st_has_mask = 0; double st_wbytes = 0; const int* st_jmin = nullptr;   // inputs of the lazy decode_algo_bytes
     // decode graph
     hipGraphExec_t gexec = nullptr; std::string gkey;
@@ -233,7 +240,7 @@ extern "C" void car_destroy(car_ctx* c) {
     for (auto& kv : c->resize_cache) { (void)hipFree(kv.second.iy); (void)hipFree(kv.second.ix); if (kv.second.wy) (void)hipFree(kv.second.wy); if (kv.second.wx) (void)hipFree(kv.second.wx); }
     if (c->rope) (void)hipFree(c->rope);
     c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
-    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release(); c->canny_map.release();
+    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release(); c->canny_map.release(); c->t5_in.release(); c->t5_bias.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
     (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 7; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); }
@@ -418,6 +425,46 @@ extern "C" int car_load_tensor(car_ctx* c, const char* cname, const void* ptr, c
     const car_config& g = c->cfg;
     c->finalized = false;
     // ---- name-specific packing
+    if (starts_with(name, "t5.")) {
+        // caption encoder (car_t5_encode).  A full T5 state dict may be offered: the decoder half, lm_head and the tied alias are skipped.
+        if (!c->has_t5) FAIL(c, "%s: call car_t5_configure before loading t5.* tensors", cname);
+        if (starts_with(name, "t5.decoder.") || starts_with(name, "t5.lm_head.") || name == "t5.encoder.embed_tokens.weight") return 0;
+        const car_t5_config& t = c->t5;
+        if (ends_with(name, "SelfAttention.relative_attention_bias.weight")) {
+            if (ndim != 2 || shp[0] != t.rel_buckets || shp[1] != t.num_heads) FAIL(c, "%s: expected [%d,%d]", cname, t.rel_buckets, t.num_heads);
+            if (c->mode == CAR_BF16) for (auto& v : h) v = bf2f(f2bf(v));          // nn.Embedding weight in the model dtype
+            c->host_keep[name] = h; c->t5_bias_T = 0; return 0;
+        }
+        if (ends_with(name, "DenseReluDense.wi_0.weight") || ends_with(name, "DenseReluDense.wi_1.weight")) {
+            // wi_0 | wi_1 interleaved in blocks of 16 rows: the gated epilogue sees (gate, value) pairs (same image as w1 | w3)
+            if (ndim != 2 || shp[0] != t.d_ff || shp[1] != t.d_model) FAIL(c, "%s: expected [%d,%d]", cname, t.d_ff, t.d_model);
+            const bool is0 = ends_with(name, "wi_0.weight");
+            const std::string base = name.substr(0, name.size() - strlen("wi_0.weight"));
+            const std::string other = base + (is0 ? "wi_1.weight" : "wi_0.weight");
+            auto it = c->host_keep.find(other);
+            if (it == c->host_keep.end()) { c->host_keep[name] = std::move(h); return 0; }
+            const std::vector<float>& w0 = is0 ? h : it->second; const std::vector<float>& w1 = is0 ? it->second : h;
+            std::vector<float> pk((size_t)2 * t.d_ff * t.d_model);
+            for (int r = 0; r < t.d_ff; ++r) {
+                const size_t blk = (size_t)(r / 16) * 32 + (r % 16);
+                memcpy(&pk[blk * t.d_model], &w0[(size_t)r * t.d_model], (size_t)t.d_model * 4);
+                memcpy(&pk[(blk + 16) * t.d_model], &w1[(size_t)r * t.d_model], (size_t)t.d_model * 4);
+            }
+            int rc = upload(c, base + "wi.weight", pk, {2 * (int64_t)t.d_ff, t.d_model});
+            c->host_keep.erase(other);
+            return rc;
+        }
+        const int inner = t.num_heads * t.d_kv;
+        int64_t e0 = -1, e1 = -1;
+        if (name == "t5.shared.weight") { e0 = t.vocab_size; e1 = t.d_model; }
+        else if (ends_with(name, "SelfAttention.q.weight") || ends_with(name, "SelfAttention.k.weight") || ends_with(name, "SelfAttention.v.weight")) { e0 = inner; e1 = t.d_model; }
+        else if (ends_with(name, "SelfAttention.o.weight")) { e0 = t.d_model; e1 = inner; }
+        else if (ends_with(name, "DenseReluDense.wo.weight")) { e0 = t.d_model; e1 = t.d_ff; }
+        else if (ends_with(name, "layer_norm.weight")) { e0 = t.d_model; }
+        else FAIL(c, "%s: not a tensor of the T5 encoder (gated-gelu family)", cname);
+        if (shp.empty() || shp[0] != e0 || (e1 >= 0 && (ndim != 2 || shp[1] != e1)) || (e1 < 0 && ndim != 1)) FAIL(c, "%s: unexpected shape", cname);
+        return upload(c, name, h, shp);
+    }
     if (ends_with(name, "feed_forward.w1.weight") || ends_with(name, "feed_forward.w3.weight")) {
         // w1 | w3 interleaved in blocks of 16 rows so the GEMM epilogue sees (a, c) pairs (gemm.hip SWIGLU)
         if (ndim != 2 || shp[0] != g.ffn_hidden || shp[1] != g.dim) FAIL(c, "%s: expected [%d,%d]", cname, g.ffn_hidden, g.dim);
@@ -540,8 +587,20 @@ extern "C" int car_finalize_weights(car_ctx* c) {
     std::string missing;
     int nmiss = 0;
     // a context may serve only decode_code (VQ weights alone) — the reference keeps GPT and VQ as separate modules
-    const bool vq_only = Wp(c, "quantize.embedding.weight") && !Wp(c, "tok_embeddings.weight") && !Wp(c, "output.weight");
+    const bool have_t5 = c->has_t5 && Wp(c, "t5.shared.weight");
+    const bool vq_only = (Wp(c, "quantize.embedding.weight") || have_t5) && !Wp(c, "tok_embeddings.weight") && !Wp(c, "output.weight");
     c->has_gpt = !vq_only;
+    if (have_t5) {       // the caption encoder is optional as a group, complete if present
+        std::vector<std::string> tr = {"t5.encoder.final_layer_norm.weight"};
+        for (int i = 0; i < c->t5.num_layers; ++i) {
+            const std::string p = "t5.encoder.block." + std::to_string(i) + ".layer.";
+            for (const char* s : {"0.SelfAttention.q.weight", "0.SelfAttention.k.weight", "0.SelfAttention.v.weight", "0.SelfAttention.o.weight", "0.layer_norm.weight",
+                                  "1.DenseReluDense.wi.weight", "1.DenseReluDense.wo.weight", "1.layer_norm.weight"}) tr.push_back(p + s);
+        }
+        for (auto& r : tr) if (!Wp(c, r)) { if (nmiss < 6) missing += r + " "; ++nmiss; }
+        if (c->host_keep.find("t5.encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight") == c->host_keep.end()) {
+            missing += "t5.encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight "; ++nmiss; }
+    }
     if (!vq_only) {
         for (auto& r : req) if (!Wp(c, r)) { if (nmiss < 6) missing += r + " "; ++nmiss; }
         if (c->host_keep.find("adapter.model.embeddings.position_embeddings") == c->host_keep.end()) { missing += "adapter.model.embeddings.position_embeddings "; ++nmiss; }
@@ -1354,6 +1413,137 @@ extern "C" int car_debug_control_tokens(car_ctx* c, int32_t k, float* host_out, 
     else { std::vector<bf16_t> hb(n); HIPCHK(c, hipMemcpy(hb.data(), c->ctrl[k].p, n * 2, hipMemcpyDeviceToHost)); for (size_t i = 0; i < n; ++i) host_out[i] = bf2f(hb[i]); }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------- caption encoder
+// HF T5EncoderModel as the reference builds it (language/t5.py:58-79) and calls it (:185-201): T5Stack of
+// [T5LayerSelfAttention, T5LayerFF] blocks (modeling_t5.py), pre-RMSNorm residual layout, no biases anywhere, relative position
+// bias of block 0 shared by every block, attention scaling 1.0, gated tanh-GELU feed-forward, final RMSNorm.
+extern "C" int car_t5_configure(car_ctx* c, const car_t5_config* t) {
+    if (!c || !t) { if (c) c->err = "car_t5_configure: null argument"; return -1; }
+    if (t->vocab_size <= 0 || t->d_model <= 0 || t->d_kv <= 0 || t->num_heads <= 0 || t->d_ff <= 0 || t->num_layers <= 0 || t->rel_buckets < 4 ||
+        t->rel_max_distance <= 0 || !(t->ln_eps > 0.f)) FAIL(c, "car_t5_configure: non-positive field");
+    if (t->d_model % 32 || t->d_kv % 32 || t->d_ff % 32 || t->d_model > 16384) FAIL(c, "car_t5_configure: d_model, d_kv, d_ff must be multiples of 32 (d_model <= 16384)");
+    if (t->rel_buckets % 4) FAIL(c, "car_t5_configure: rel_buckets must be a multiple of 4");
+    c->t5 = *t; c->has_t5 = true; c->t5_bias_T = 0;
+    return 0;
+}
+
+// T5Attention._relative_position_bucket, bidirectional (modeling_t5.py): rel = key - query
+static int t5_bucket(int rel, int nb, int max_distance) {
+    int b = 0; const int n = nb / 2;
+    if (rel > 0) b += n;
+    const int a = rel < 0 ? -rel : rel, max_exact = n / 2;
+    if (a < max_exact) return b + a;
+    int v = max_exact + (int)(std::log((double)a / max_exact) / std::log((double)max_distance / max_exact) * (n - max_exact));
+    if (v > n - 1) v = n - 1;
+    return b + v;
+}
+
+extern "C" int car_t5_encode(car_ctx* c, const int64_t* input_ids, const int64_t* attention_mask, int32_t B, int32_t T, void* out, void* stream_) {
+    if (!c) return -1;
+    if (!c->has_t5 || !c->finalized || !Wp(c, "t5.shared.weight")) FAIL(c, "car_t5_encode: T5 weights not loaded / finalised");
+    if (!input_ids || !out || B <= 0 || T <= 0) FAIL(c, "car_t5_encode: bad arguments");
+    const car_t5_config& t = c->t5;
+    const int mode = c->mode; const size_t e = c->esz;
+    const int D = t.d_model, nh = t.num_heads, hd = t.d_kv, inner = nh * hd, F = t.d_ff, Tpad = (int)rup(T, 32);
+    hipStream_t caller = (hipStream_t)stream_, st = c->stream;
+    // position bias [heads][T][T] for this T (compute_bias): table[bucket(j - i)][h]
+    if (c->t5_bias_T != T) {
+        const std::vector<float>& tab = c->host_keep["t5.encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"];
+        std::vector<float> hb((size_t)nh * T * T);
+        std::vector<int> bk(2 * T - 1);
+        for (int r = -(T - 1); r <= T - 1; ++r) bk[r + T - 1] = t5_bucket(r, t.rel_buckets, t.rel_max_distance);
+        for (int h = 0; h < nh; ++h) for (int i = 0; i < T; ++i) for (int j = 0; j < T; ++j)
+            hb[((size_t)h * T + i) * T + j] = tab[(size_t)bk[j - i + T - 1] * nh + h];
+        HIPCHK(c, hipStreamSynchronize(st));
+        NEED(c, c->t5_bias, hb.size() * 4);
+        HIPCHK(c, hipMemcpy(c->t5_bias.p, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+        c->t5_bias_T = T;
+    }
+    const long n_tok = (long)B * T;
+    // ids int32 | mask uint8 | int64 staging for host-side inputs
+    const size_t o_mk = rup((size_t)n_tok * 4, 256), o_st = o_mk + rup((size_t)n_tok, 256);
+    NEED(c, c->t5_in, o_st + 2 * (size_t)n_tok * 8);
+    int* ids32 = (int*)c->t5_in.p; unsigned char* mk = (unsigned char*)c->t5_in.p + o_mk; long long* stage = (long long*)((char*)c->t5_in.p + o_st);
+    int CH = B; if (CH > 64) CH = 64;
+    const long rows_max = (long)CH * T;
+    NEED(c, c->ws[1], (size_t)n_tok * D * e);                 // h (all rows: gathered up front)
+    NEED(c, c->ws[2], (size_t)rows_max * D * e);              // xn
+    NEED(c, c->ws[3], (size_t)rows_max * 3 * inner * e);      // q | k | v planes
+    NEED(c, c->ws[4], (size_t)CH * nh * T * T * 4);           // S fp32
+    NEED(c, c->ws[5], (size_t)CH * nh * T * Tpad * e);        // P
+    NEED(c, c->ws[6], (size_t)CH * inner * Tpad * e);         // V^T
+    NEED(c, c->ws[7], (size_t)rows_max * F * e);              // gated mid
+    NEED(c, c->ws[8], (size_t)rows_max * inner * e);          // ctx
+    if (mode == CAR_F32) NEED(c, c->ws[9], (size_t)rows_max * 2 * F * e);   // exact mode: wi_0 | wi_1 outputs before the gate
+    fence_in(c, caller);
+    auto on_device = [](const void* p) { hipPointerAttribute_t at; if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+                                         return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged; };
+    const long long* d_ids = (const long long*)input_ids; const long long* d_mask = (const long long*)attention_mask;
+    if (!on_device(input_ids)) { HIPCHK(c, hipMemcpyAsync(stage, input_ids, (size_t)n_tok * 8, hipMemcpyHostToDevice, st)); d_ids = stage; }
+    if (attention_mask && !on_device(attention_mask)) { HIPCHK(c, hipMemcpyAsync(stage + n_tok, attention_mask, (size_t)n_tok * 8, hipMemcpyHostToDevice, st)); d_mask = stage + n_tok; }
+    car_launch_t5_prep(d_ids, d_mask, ids32, mk, n_tok, t.vocab_size, st);
+    car_launch_gather_rows(mode, Wp(c, "t5.shared.weight"), ids32, c->ws[1].p, n_tok, D, st);
+    const float* bias = (const float*)c->t5_bias.p;
+    for (int b0 = 0; b0 < B; b0 += CH) {
+        const int nb = (B - b0) < CH ? (B - b0) : CH;
+        const long rows = (long)nb * T;
+        void *h = off(c->ws[1].p, (size_t)b0 * T * D, e), *xn = c->ws[2].p, *qkv = c->ws[3].p, *P = c->ws[5].p, *vT = c->ws[6].p, *mid = c->ws[7].p, *ctx = c->ws[8].p;
+        float* S = (float*)c->ws[4].p;
+        void* qp = qkv; void* kp = off(qkv, (size_t)rows * inner, e); void* vp = off(qkv, (size_t)2 * rows * inner, e);
+        auto norm = [&](const std::string& w, void* dst) {
+            NormP np; memset(&np, 0, sizeof(np)); np.h_in = h; np.xn = dst; np.w = Wp(c, w); np.D = D; np.eps = t.ln_eps;
+            car_launch_rmsnorm(mode, &np, rows, st);
+        };
+        for (int l = 0; l < t.num_layers; ++l) {
+            const std::string L = "t5.encoder.block." + std::to_string(l) + ".layer.";
+            norm(L + "0.layer_norm.weight", xn);
+            const char* names[3] = {"q", "k", "v"}; void* dst[3] = {qp, kp, vp};
+            for (int k = 0; k < 3; ++k) {
+                GemmP q = gp(xn, D, Wp(c, L + "0.SelfAttention." + names[k] + ".weight"), D, dst[k], inner, (int)rows, inner, D);
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            }
+            {   // scores[b,h] = Q K^T (scaling 1.0)
+                GemmP q = gp(qp, inner, kp, inner, S, T, T, T, hd);
+                q.out_f32 = 1; q.nb0 = nb; q.nb1 = nh;
+                q.sA0 = (long)T * inner; q.sA1 = hd; q.sW0 = (long)T * inner; q.sW1 = hd; q.sC0 = (long)nh * T * T; q.sC1 = (long)T * T;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            }
+            car_launch_t5_softmax(mode, S, T, P, Tpad, (long)nb * nh * T, T, bias, mk + (size_t)b0 * T, T, nh, st);
+            car_launch_transpose_pad(mode, vp, inner, (long)T * inner, vT, nb, T, Tpad, inner, st);
+            {   // ctx[b, t, h*hd + d] = P[b,h] @ V[b,h]
+                GemmP q = gp(P, Tpad, vT, Tpad, ctx, inner, T, hd, Tpad);
+                q.nb0 = nb; q.nb1 = nh;
+                q.sA0 = (long)nh * T * Tpad; q.sA1 = (long)T * Tpad; q.sW0 = (long)inner * Tpad; q.sW1 = (long)hd * Tpad; q.sC0 = (long)T * inner; q.sC1 = hd;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            }
+            {   // h = h + o(ctx)   (T5LayerSelfAttention)
+                GemmP q = gp(ctx, inner, Wp(c, L + "0.SelfAttention.o.weight"), inner, h, D, (int)rows, D, inner);
+                q.R = h; q.ldr = D;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            }
+            norm(L + "1.layer_norm.weight", xn);
+            if (mode == CAR_BF16) {   // mid = gelu_new(wi_0 x) * wi_1 x in the GEMM epilogue
+                GemmP q = gp(xn, D, Wp(c, L + "1.DenseReluDense.wi.weight"), D, mid, F, (int)rows, 2 * F, D); q.swiglu = 2;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            } else {
+                GemmP q = gp(xn, D, Wp(c, L + "1.DenseReluDense.wi.weight"), D, c->ws[9].p, 2 * F, (int)rows, 2 * F, D);
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+                car_launch_t5_gated_act(mode, c->ws[9].p, mid, rows, F, st);
+            }
+            {   // h = h + wo(mid)   (T5LayerFF)
+                GemmP q = gp(mid, F, Wp(c, L + "1.DenseReluDense.wo.weight"), F, h, D, (int)rows, D, F);
+                q.R = h; q.ldr = D;
+                car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            }
+        }
+        norm("t5.encoder.final_layer_norm.weight", off(out, (size_t)b0 * T * D, e));
+    }
+    fence_out(c, caller);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 
 // ------------------------------------------------------------------------------------- Canny control extraction
 // cv2.Canny(img, low, high) of condition/canny.py:6-14 for a batch of 8-bit RGB photos [B,H,W,3] (device).  edges_out: uint8 [B,H,W] in

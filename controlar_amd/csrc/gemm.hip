@@ -78,6 +78,8 @@ __device__ __forceinline__ void ld8bf(const bf16_t* p, float (&v)[8]) {
     for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
 }
 enum { EP_VEC = 0, EP_SCALAR = 1, EP_SWIGLU = 2 };
+// gate of the paired-column epilogue: GemmP::swiglu 1 = SiLU (LlamaGen FeedForward), 2 = tanh-GELU (T5 gated-gelu, "gelu_new")
+__device__ __forceinline__ float gate_act(int kind, float a) { return kind == 2 ? gelu_tanh_f(a) : silu_f(a); }
 __device__ __forceinline__ int strip_path(const GemmP& p, long zC, long zR) {
     if (p.swiglu) return EP_SWIGLU;
     const bool vec = (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0) && p.bias_mode != BIAS_M &&
@@ -96,7 +98,7 @@ __device__ __forceinline__ void store_strip(const GemmP& p, const float* strip, 
             for (int e = 0; e < 8; e += 2) {
                 const float a0 = bf2f(f2bf(strip[rr * 68 + src + e])), c0 = bf2f(f2bf(strip[rr * 68 + src + 16 + e]));
                 const float a1 = bf2f(f2bf(strip[rr * 68 + src + e + 1])), c1 = bf2f(f2bf(strip[rr * 68 + src + 17 + e]));
-                o[e >> 1] = (unsigned)f2bf(bf2f(f2bf(silu_f(a0))) * c0) | ((unsigned)f2bf(bf2f(f2bf(silu_f(a1))) * c1) << 16);
+                o[e >> 1] = (unsigned)f2bf(bf2f(f2bf(gate_act(p.swiglu, a0))) * c0) | ((unsigned)f2bf(bf2f(f2bf(gate_act(p.swiglu, a1))) * c1) << 16);
             }
             *(uint4*)((bf16_t*)p.C + zC + out_row(p, m) * p.ldc + (nb >> 1) + c) = make_uint4(o[0], o[1], o[2], o[3]);
         } else if (m < p.M) {
@@ -104,7 +106,7 @@ __device__ __forceinline__ void store_strip(const GemmP& p, const float* strip, 
                 const int n = nb + src + e;
                 if (n + 16 < p.N) {
                     const float a1 = bf2f(f2bf(strip[rr * 68 + src + e])), c3 = bf2f(f2bf(strip[rr * 68 + src + 16 + e]));
-                    ((bf16_t*)p.C)[zC + out_row(p, m) * p.ldc + (nb >> 1) + c + e] = f2bf(bf2f(f2bf(silu_f(a1))) * c3);
+                    ((bf16_t*)p.C)[zC + out_row(p, m) * p.ldc + (nb >> 1) + c + e] = f2bf(bf2f(f2bf(gate_act(p.swiglu, a1))) * c3);
                 }
             }
         }

@@ -212,6 +212,31 @@ class Engine:
         edges = edges[0] if single else edges
         return (edges, ctrl) if want_control else edges
 
+    # ------------------------------------------------------------------ caption encoder (language/t5.py)
+    def t5_configure(self, t5cfg):
+        tc = L.CarT5Config()
+        tc.vocab_size, tc.d_model, tc.d_kv, tc.num_heads = t5cfg.vocab_size, t5cfg.d_model, t5cfg.d_kv, t5cfg.num_heads
+        tc.d_ff, tc.num_layers = t5cfg.d_ff, t5cfg.num_layers
+        tc.rel_buckets, tc.rel_max_distance = t5cfg.relative_attention_num_buckets, t5cfg.relative_attention_max_distance
+        tc.ln_eps = t5cfg.layer_norm_epsilon
+        self._check(self.lib.car_t5_configure(self._h, C.byref(tc)), "car_t5_configure")
+        self.t5cfg = t5cfg
+
+    def load_t5_state_dict(self, sd: Dict[str, torch.Tensor], finalize: bool = True):
+        """HF T5EncoderModel / T5ForConditionalGeneration state-dict names; the C ABI namespaces them under 't5.'."""
+        self.load_state_dict({"t5." + k: v for k, v in sd.items()}, finalize=finalize)
+
+    def t5_encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """T5EncoderModel(input_ids, attention_mask)['last_hidden_state'] (language/t5.py:194-199) -> [B,T,d_model] in self.dtype."""
+        assert input_ids.dim() == 2
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mk = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        B, T = ids.shape
+        out = torch.empty(B, T, self.t5cfg.d_model, dtype=self.dtype, device=self.device)
+        self._check(self.lib.car_t5_encode(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(mk.data_ptr() if mk is not None else 0), B, T,
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(_stream_ptr())), "car_t5_encode")
+        return out
+
     def stats(self) -> dict:
         s = L.CarStats()
         self._check(self.lib.car_get_stats(self._h, C.byref(s)), "car_get_stats")

@@ -15,7 +15,7 @@ from typing import Dict
 
 import torch
 
-from .config import PathConfig, GPTConfig, ViTConfig, VQConfig
+from .config import PathConfig, GPTConfig, ViTConfig, VQConfig, T5Config
 
 
 class _Rng:
@@ -305,3 +305,44 @@ def text_embeddings(batch: int, T: int = 120, caption_dim: int = 2048, seed: int
         embs.append(e * m[:, None])
         masks.append(m)
     return torch.stack(embs), torch.stack(masks)
+
+
+def t5_state_dict(cfg: T5Config, seed: int = 7) -> Dict[str, torch.Tensor]:
+    """HF T5EncoderModel.state_dict() names (shared.weight, encoder.block.N.layer.{0,1}.*, encoder.final_layer_norm.weight).
+    Scales follow T5PreTrainedModel._init_weights (q: (d_model*d_kv)^-0.5 because attention is unscaled; k, v, wi: d_model^-0.5;
+    o: (heads*d_kv)^-0.5; wo: d_ff^-0.5) except that norms are 1 + 0.1 N and the relative bias is N(0, 0.5^2) so both matter."""
+    r = _Rng(seed)
+    D, kv, H, F = cfg.d_model, cfg.d_kv, cfg.num_heads, cfg.d_ff
+    inner = H * kv
+    sd = {"shared.weight": r.normal(cfg.vocab_size, D)}
+    for i in range(cfg.num_layers):
+        a = f"encoder.block.{i}.layer.0."
+        sd[a + "SelfAttention.q.weight"] = r.normal(inner, D, std=(D * kv) ** -0.5 * 2.0)
+        sd[a + "SelfAttention.k.weight"] = r.normal(inner, D, std=D ** -0.5)
+        sd[a + "SelfAttention.v.weight"] = r.normal(inner, D, std=D ** -0.5)
+        sd[a + "SelfAttention.o.weight"] = r.normal(D, inner, std=inner ** -0.5)
+        if i == 0:
+            sd[a + "SelfAttention.relative_attention_bias.weight"] = r.normal(cfg.relative_attention_num_buckets, H, std=0.5)
+        sd[a + "layer_norm.weight"] = 1.0 + 0.1 * r.normal(D)
+        f = f"encoder.block.{i}.layer.1."
+        sd[f + "DenseReluDense.wi_0.weight"] = r.normal(F, D, std=D ** -0.5)
+        sd[f + "DenseReluDense.wi_1.weight"] = r.normal(F, D, std=D ** -0.5)
+        sd[f + "DenseReluDense.wo.weight"] = r.normal(D, F, std=F ** -0.5)
+        sd[f + "layer_norm.weight"] = 1.0 + 0.1 * r.normal(D)
+    sd["encoder.final_layer_norm.weight"] = 1.0 + 0.1 * r.normal(D)
+    return sd
+
+
+def t5_tokens(batch: int, cfg: T5Config, seed: int = 4321, lengths=None):
+    """Tokenizer-shaped inputs: ids RIGHT-padded with 0 to model_max_length (HF T5 tokenizer pads right; the reference left-pads
+    the EMBEDDINGS afterwards, sample_t2i.py:146-160), last valid id = 1 (</s>), attention_mask 1 on valid positions."""
+    T = cfg.model_max_length
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(batch, T, dtype=torch.int64)
+    mask = torch.zeros(batch, T, dtype=torch.int64)
+    for b in range(batch):
+        L = int(lengths[b]) if lengths is not None else int(torch.randint(4, min(41, T + 1), (1,), generator=g).item())
+        ids[b, :L - 1] = torch.randint(2, cfg.vocab_size, (L - 1,), generator=g)
+        ids[b, L - 1] = 1
+        mask[b, :L] = 1
+    return ids, mask

@@ -149,6 +149,37 @@ int car_canny(car_ctx* ctx, const uint8_t* img_hwc, int32_t B, int32_t H, int32_
               uint8_t* edges_out, void* control_out, void* stream);
 
 /*
+ * Caption encoder — replaces T5Embedder.get_text_embeddings' model call (language/t5.py:185-201:
+ * self.model(input_ids, attention_mask)['last_hidden_state'], HF T5EncoderModel built at language/t5.py:58-79; callers
+ * sample_t2i.py:99-118, demo/model.py).  The tokenizer stays on the host side of the boundary (sentencepiece, CPU string work).
+ * Configure once, load the encoder's tensors through car_load_tensor under the names "t5." + the HF state-dict key
+ * (shared.weight, encoder.block.N.layer.0.SelfAttention.{q,k,v,o}.weight, ...relative_attention_bias.weight (block 0),
+ * encoder.block.N.layer.0.layer_norm.weight, encoder.block.N.layer.1.DenseReluDense.{wi_0,wi_1,wo}.weight,
+ * encoder.block.N.layer.1.layer_norm.weight, encoder.final_layer_norm.weight; encoder.embed_tokens.weight is the tied alias of
+ * shared.weight and is ignored), then car_finalize_weights.  A context may hold the T5 encoder alone or next to a GPT / VQ model.
+ */
+typedef struct car_t5_config {
+    int32_t vocab_size;       /* 32128 */
+    int32_t d_model;          /* 2048 (Flan-T5-XL) */
+    int32_t d_kv;             /* 64 */
+    int32_t num_heads;        /* 32 */
+    int32_t d_ff;             /* 5120 */
+    int32_t num_layers;       /* 24 */
+    int32_t rel_buckets;      /* relative_attention_num_buckets, 32 */
+    int32_t rel_max_distance; /* relative_attention_max_distance, 128 */
+    float   ln_eps;           /* layer_norm_epsilon, 1e-6 */
+    int32_t reserved[7];
+} car_t5_config;
+int car_t5_configure(car_ctx* ctx, const car_t5_config* cfg);
+/*
+ * input_ids, attention_mask: int64 [B,T] (device or host; attention_mask may be NULL = all ones).  out: [B,T,d_model] in the
+ * context's element type (device) = last_hidden_state (final_layer_norm applied; dropout is identity in eval).  Rows at padded
+ * positions are computed exactly as HF computes them (only KEYS are masked).  feature_type "gated-gelu" (gelu_new) only — the
+ * family the reference loads (flan-t5-xl, t5-v1_1-xxl).
+ */
+int car_t5_encode(car_ctx* ctx, const int64_t* input_ids, const int64_t* attention_mask, int32_t B, int32_t T, void* out, void* stream);
+
+/*
  * generate() for the class-conditional model — replaces generate.py:134-204 (c2i branch :139-154) over
  * autoregressive/models/gpt.py.  labels [B] int64 (device).  Prefix length is 1; no pad mask; control_strength
  * does not exist on this path.  NOTE: in the reference snapshot this branch only runs with cfg_scale <= 1

@@ -375,6 +375,43 @@ CASES["vq_encode_tiny"] = lambda: case_vq_encode("vq_encode_tiny", C.tiny_t2i().
 CASES["vq_encode_vq16_64x64"] = lambda: case_vq_encode("vq_encode_vq16_64x64", C.VQConfig(), 64, 64)
 
 
+# ----------------------------------------------------------------------------------------- caption encoder (language/t5.py)
+def build_hf_t5(cfg, sd, dtype):
+    """HF T5EncoderModel exactly as T5Embedder.__init__ gets it from from_pretrained (language/t5.py:78), random-init of the
+    configured size, weights overwritten with the synthetic state dict, eager attention (the explicit matmul/softmax path)."""
+    from transformers import T5Config, T5EncoderModel
+    hc = T5Config(vocab_size=cfg.vocab_size, d_model=cfg.d_model, d_kv=cfg.d_kv, d_ff=cfg.d_ff, num_layers=cfg.num_layers,
+                  num_heads=cfg.num_heads, relative_attention_num_buckets=cfg.relative_attention_num_buckets,
+                  relative_attention_max_distance=cfg.relative_attention_max_distance, layer_norm_epsilon=cfg.layer_norm_epsilon,
+                  feed_forward_proj="gated-gelu", dropout_rate=0.1, attn_implementation="eager")
+    m = T5EncoderModel(hc)
+    full = dict(sd)
+    full["encoder.embed_tokens.weight"] = sd["shared.weight"]
+    missing, unexpected = m.load_state_dict(full, strict=False)
+    assert not unexpected and all("embed_tokens" in k or "shared" in k for k in missing), (missing, unexpected)
+    return m.to(dtype).eval()
+
+
+def case_t5(name, cfg, B, lengths=None, threads=8, with_bf16=True):
+    torch.set_num_threads(threads)
+    sd = synth.t5_state_dict(cfg)
+    ids, mask = synth.t5_tokens(B, cfg, lengths=lengths)
+    t0 = time.time()
+    with torch.no_grad():
+        out = build_hf_t5(cfg, sd, torch.float32)(input_ids=ids, attention_mask=mask)["last_hidden_state"]
+        arrs = dict(input_ids=ids.numpy(), attention_mask=mask.numpy(), out=out.numpy())
+        if with_bf16:      # the reference runs the encoder in bf16 (sample_t2i.py:104): its own round-off vs fp32 calibrates the bf16 tolerance
+            ob = build_hf_t5(cfg, sd, torch.bfloat16)(input_ids=ids, attention_mask=mask)["last_hidden_state"]
+            arrs["out_bf16"] = ob.float().numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print(f"{name}: {time.time() - t0:.1f}s  |out| max {out.abs().max():.3f} mean {out.abs().mean():.3f}")
+
+
+CASES["t5_tiny"] = lambda: case_t5("t5_tiny", C.tiny_t5(), 3, lengths=[1, 17, 120])
+CASES["t5_small"] = lambda: case_t5("t5_small", C.small_t5(), 2)
+CASES["t5_flan_xl"] = lambda: case_t5("t5_flan_xl", C.flan_t5_xl(), 1, lengths=[23], with_bf16=False)   # full size; fp32 only (1.2 B params)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or DEFAULT
     for n in names:

@@ -1,0 +1,122 @@
+"""car_t5_encode on the GPU (pytest -m gpu) against the HF T5EncoderModel goldens and the CPU oracle.
+
+Floating-point stage: exact mode (fp32) must match the fp32 golden to <= 2e-4 of the output scale (different summation order
+only); fast mode (bf16, the precision the reference runs T5 in, sample_t2i.py:104) is graded against the reference's OWN bf16
+round-off on the same inputs: mean error <= 1.5x, max error <= 2x of HF-bf16-vs-HF-fp32 (t5_small golden holds both)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _embedder(cfg, dtype, sd=None):
+    from controlar_amd import synth
+    from controlar_amd.t5 import T5Embedder
+    return T5Embedder("cuda", config=cfg, state_dict=sd if sd is not None else synth.t5_state_dict(cfg), torch_dtype=dtype)
+
+
+@pytest.mark.parametrize("name", ["t5_tiny", "t5_small"])
+def test_fp32_matches_hf_golden(name):
+    from controlar_amd import config as C
+    cfg = C.tiny_t5() if name == "t5_tiny" else C.small_t5()
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    emb = _embedder(cfg, torch.float32)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    out = emb.encode_ids(ids.cuda(), mask.cuda()).cpu().numpy()
+    ref = g["out"]
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err <= 2e-4, err
+    # host-side (pinned-less) inputs take the staging path and give the same bits
+    out2 = emb.engine.t5_encode(ids, mask).cpu().numpy()
+    assert np.array_equal(out, out2)
+    # attention_mask=None == all ones
+    a = emb.encode_ids(ids.cuda(), None).cpu().numpy()
+    b = emb.encode_ids(ids.cuda(), torch.ones_like(mask).cuda()).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
+def test_bf16_within_reference_bf16_roundoff():
+    from controlar_amd import config as C
+    cfg = C.small_t5()
+    g = np.load(os.path.join(GOLD, "t5_small.npz"))
+    emb = _embedder(cfg, torch.bfloat16)
+    out = emb.encode_ids(torch.from_numpy(g["input_ids"]).cuda(), torch.from_numpy(g["attention_mask"]).cuda()).float().cpu().numpy()
+    valid = g["attention_mask"].astype(bool)
+    hf_err = np.abs(g["out_bf16"] - g["out"])[valid]
+    my_err = np.abs(out - g["out"])[valid]
+    print("bf16 err mean/max mine", my_err.mean(), my_err.max(), "hf", hf_err.mean(), hf_err.max())
+    assert my_err.mean() <= 1.5 * hf_err.mean() + 1e-3
+    assert my_err.max() <= 2.0 * hf_err.max() + 1e-2
+
+
+def test_flan_t5_xl_full_size_fp32_and_bf16():
+    """Full-size Flan-T5-XL (24 layers, d_model 2048, 32 heads, d_ff 5120; 1.2 B parameters of synthetic weights) against the
+    HF fp32 golden minted in the build container; then bf16 against the same golden with the calibrated slack."""
+    from controlar_amd import config as C
+    from controlar_amd import synth
+    cfg = C.flan_t5_xl()
+    g = np.load(os.path.join(GOLD, "t5_flan_xl.npz"))
+    sd = synth.t5_state_dict(cfg)
+    ids, mask = torch.from_numpy(g["input_ids"]).cuda(), torch.from_numpy(g["attention_mask"]).cuda()
+    valid = g["attention_mask"].astype(bool)
+    ref = g["out"]
+    emb = _embedder(cfg, torch.float32, sd)
+    out = emb.encode_ids(ids, mask).cpu().numpy()
+    err = np.abs(out - ref)[valid].max() / np.abs(ref).max()
+    print("xl fp32 rel err", err)
+    assert err <= 5e-4, err
+    emb.engine.close()
+    embb = _embedder(cfg, torch.bfloat16, sd)
+    outb = embb.encode_ids(ids, mask).float().cpu().numpy()
+    e = np.abs(outb - ref)[valid]
+    print("xl bf16 err mean/max", e.mean(), e.max(), "scale", np.abs(ref).mean())
+    assert e.mean() <= 0.05 * np.abs(ref[valid]).mean() + 1e-3      # bf16 through 24 layers: a few % of the mean magnitude
+    # batch invariance + padding property at full size: the same prompt inside a larger batch, other rows different lengths
+    ids3, mask3 = synth.t5_tokens(3, cfg, lengths=[5, 23, 120])
+    ids3[1], mask3[1] = ids[0].cpu(), mask[0].cpu()
+    o3 = embb.encode_ids(ids3.cuda(), mask3.cuda()).float().cpu().numpy()
+    assert np.array_equal(o3[1][valid[0]], outb[0][valid[0]])
+
+
+def test_matches_oracle_on_edge_lengths():
+    """single token, full length, batch > chunk (65 prompts: two chunks of the 64-prompt scratch)"""
+    from controlar_amd import config as C
+    from controlar_amd import synth
+    from oracle import t5_oracle as TO
+    cfg = C.tiny_t5()
+    sd = synth.t5_state_dict(cfg)
+    lengths = [1, 120] + [int(3 + (7 * i) % 100) for i in range(63)]
+    ids, mask = synth.t5_tokens(len(lengths), cfg, lengths=lengths)
+    want = TO.encoder_forward(sd, cfg, ids, mask).numpy()
+    emb = _embedder(cfg, torch.float32, sd)
+    got = emb.encode_ids(ids.cuda(), mask.cuda()).cpu().numpy()
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err <= 2e-4, err
+
+
+def test_embedder_feeds_generate_like_the_sampler():
+    """sample_t2i.py:110-160: caption_embs, emb_masks = t5.get_text_embeddings(prompts); left-pad; generate().  A whitespace
+    tokenizer stands in for sentencepiece (host-side string work, outside the boundary)."""
+    from controlar_amd import config as C
+    from controlar_amd import synth
+    from controlar_amd.demo import left_pad_caption
+    from controlar_amd.t5 import T5Embedder
+    cfg = C.tiny_t5()
+
+    class Tok:
+        def __call__(self, texts, max_length, padding, truncation, return_attention_mask, add_special_tokens, return_tensors):
+            ids = torch.zeros(len(texts), max_length, dtype=torch.int64); m = torch.zeros_like(ids)
+            for i, t in enumerate(texts):
+                w = [2 + (hash(x) % (cfg.vocab_size - 2)) for x in t.split()][: max_length - 1] + [1]
+                ids[i, : len(w)] = torch.tensor(w); m[i, : len(w)] = 1
+            return {"input_ids": ids, "attention_mask": m}
+
+    emb = T5Embedder("cuda", config=cfg, state_dict=synth.t5_state_dict(cfg), tokenizer=Tok(), torch_dtype=torch.bfloat16)
+    e, m = emb.get_text_embeddings(["A Quiet  Harbor at dawn ", "two cats"])
+    assert e.shape == (2, 120, cfg.d_model) and e.dtype == torch.bfloat16 and m.shape == (2, 120) and m.sum().item() == 6 + 3
+    c, cm = left_pad_caption(e, m)
+    assert cm[:, -1].all() and torch.equal(c[0, -6:], e[0, :6]) and float(c[0, :-6].abs().max()) == 0.0
