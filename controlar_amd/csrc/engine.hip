@@ -76,6 +76,12 @@ void car_launch_t5_prep(const long long* ids, const long long* mask, int* ids32,
 void car_launch_t5_softmax(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, const float* bias,
                            const unsigned char* mask, int Tq, int n_head, hipStream_t st);
 void car_launch_t5_gated_act(int mode, const void* in, void* out, long rows, int hidden, hipStream_t st);
+struct FlashP {
+    const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* o;
+    long q_sb, q_st, k_sb, k_st; long vt_sb; int vt_ld; long o_sb, o_st;
+    int Tq, Tk, H; float scale; int mode; const unsigned char* mask; const float* bias;
+};
+int car_launch_flash64(const FlashP* p, int B, hipStream_t st);
 void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
 void car_launch_convert(int mode, const void* src, int src_dtype, void* dst, long n, hipStream_t st);
 void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg, hipStream_t st);
@@ -801,8 +807,15 @@ static GemmP gp(const void* A, long lda, const void* W, long ldw, void* C, long 
     p.alpha = 1.f; p.nb0 = 1; p.nb1 = 1;
     return p;
 }
+// fused attention (attn.hip) is the fast-mode path for 64-wide heads; CAR_NO_FLASH=1 keeps the unfused GEMM/softmax/GEMM form (A/B runs)
+static bool use_flash(const car_ctx* c, int head_dim);
 static inline char* off(void* p, size_t elems, size_t esz) { return (char*)p + elems * esz; }
 static inline const char* off(const void* p, size_t elems, size_t esz) { return (const char*)p + elems * esz; }
+
+static bool use_flash(const car_ctx* c, int head_dim) {
+    static const bool off_env = getenv("CAR_NO_FLASH") != nullptr;
+    return c->mode == CAR_BF16 && head_dim == 64 && !off_env;
+}
 
 // y = fc2(gelu_tanh(fc1 x))   (gpt_t2i.py:165-181), x: [z][M, K] with row stride lda / batch stride sA
 static void mlp_tanh(car_ctx* c, const void* x, long lda, long sA, int nb, int M, int K, const std::string& pfx, void* mid, void* y, int dim, hipStream_t st) {
@@ -832,13 +845,17 @@ extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype
     void* pos = nullptr; if (get_pos_embed(c, gh, gw, &pos)) return -1;
     NEED(c, c->ctrl_in, (size_t)B * n * g.dim * e);
     c->ctrl_B = B; c->ctrl_ntok = n;
-    const int CH = B < 16 ? B : 16;    // images per chunk: bounds the fp32 score matrix (CH*heads*Tn*Tn*4 B)
+    const bool flash = use_flash(c, hd);
+    const int chmax = flash ? 64 : 16;  // images per chunk: the unfused form is bounded by its fp32 score matrix (CH*heads*Tn*Tn*4 B)
+    const int CH = B < chmax ? B : chmax;
     NEED(c, c->ws[0], (size_t)CH * n * Kp * e);            // patches, later ctx
     NEED(c, c->ws[1], (size_t)CH * Tn * D * e);            // h
     NEED(c, c->ws[2], (size_t)CH * Tn * D * e);            // y (normed) / tok
     NEED(c, c->ws[3], (size_t)CH * Tn * 3 * D * e);        // q | k | v (separate planes)
-    NEED(c, c->ws[4], (size_t)CH * nh * Tn * Tn * 4);      // S fp32
-    NEED(c, c->ws[5], (size_t)CH * nh * Tn * Tpad * e);    // P
+    if (!flash) {
+        NEED(c, c->ws[4], (size_t)CH * nh * Tn * Tn * 4);      // S fp32
+        NEED(c, c->ws[5], (size_t)CH * nh * Tn * Tpad * e);    // P
+    }
     NEED(c, c->ws[6], (size_t)CH * D * Tpad * e);          // V^T
     NEED(c, c->ws[7], (size_t)CH * Tn * (g.vit_mlp > g.dim ? g.vit_mlp : g.dim) * e);   // mlp mid / adapter mid
     NEED(c, c->ws[8], (size_t)CH * Tn * D * e);            // ctx
@@ -868,15 +885,23 @@ extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype
                 q.bias = Wp(c, L + "attention.attention." + std::string(names[t]) + ".bias"); q.bias_mode = BIAS_N;
                 car_launch_gemm(mode, AMODE_PLAIN, &q, st);
             }
-            {   // S[b,h] = (Q K^T) * hd^-0.5   (HF eager_attention_forward :153-179; softmax internals fp32)
+            car_launch_transpose_pad(mode, vp, D, (long)Tn * D, vT, nb, Tn, Tpad, D, st);
+            bool fused = false;
+            if (flash) {
+                FlashP f; memset(&f, 0, sizeof(f));
+                f.q = (const bf16_t*)qp; f.k = (const bf16_t*)kp; f.vt = (const bf16_t*)vT; f.o = (bf16_t*)ctx;
+                f.q_sb = f.k_sb = f.o_sb = (long)Tn * D; f.q_st = f.k_st = f.o_st = D; f.vt_sb = (long)D * Tpad; f.vt_ld = Tpad;
+                f.Tq = f.Tk = Tn; f.H = nh; f.scale = 1.0f / std::sqrt((float)hd); f.mode = 0;
+                fused = car_launch_flash64(&f, nb, st) == 0;
+            }
+            if (!fused) {   // S[b,h] = (Q K^T) * hd^-0.5   (HF eager_attention_forward :153-179; softmax internals fp32)
                 GemmP q = gp(qp, D, kp, D, S, Tn, Tn, Tn, hd);
                 q.alpha = 1.0f / std::sqrt((float)hd); q.out_f32 = 1; q.nb0 = nb; q.nb1 = nh;
                 q.sA0 = (long)Tn * D; q.sA1 = hd; q.sW0 = (long)Tn * D; q.sW1 = hd; q.sC0 = (long)nh * Tn * Tn; q.sC1 = (long)Tn * Tn;
                 car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+                car_launch_softmax(mode, S, Tn, P, Tpad, (long)nb * nh * Tn, Tn, 0, nullptr, 0, 0, st);
             }
-            car_launch_softmax(mode, S, Tn, P, Tpad, (long)nb * nh * Tn, Tn, 0, nullptr, 0, 0, st);
-            car_launch_transpose_pad(mode, vp, D, (long)Tn * D, vT, nb, Tn, Tpad, D, st);
-            {   // ctx[b, t, h*hd + d] = P[b,h] @ V[b,h]
+            if (!fused) {   // ctx[b, t, h*hd + d] = P[b,h] @ V[b,h]
                 GemmP q = gp(P, Tpad, vT, Tpad, ctx, D, Tn, hd, Tpad);
                 q.nb0 = nb; q.nb1 = nh;
                 q.sA0 = (long)nh * Tn * Tpad; q.sA1 = (long)Tn * Tpad; q.sW0 = (long)D * Tpad; q.sW1 = (long)hd * Tpad; q.sC0 = (long)Tn * D; q.sC1 = hd;
@@ -1204,6 +1229,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         }
     }
     // ---- E. prefill over the T prefix rows (gpt_t2i.py:446-470)
+    const bool pf_flash = use_flash(c, 64);
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
         {
@@ -1215,15 +1241,23 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         { GemmP q = gp(xn, D, Wp(c, L + "attention.wqkv.weight"), D, qkv, 3 * D, (int)rowsP, 3 * D, D); car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
         if (fast) car_launch_prefill_rope_kv2(qkv, off(c->kv.p, (size_t)(2 * l) * kv_layer, e), off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e), c->rope, b, T, Hn, D, SA, st);
         else car_launch_prefill_rope_kv(mode, qkv, off(c->kv.p, (size_t)(2 * l) * kv_layer, e), off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e), c->rope, b, T, Hn, D, S_max, st);
-        {
+        car_launch_transpose_pad(mode, off(qkv, (size_t)2 * D, e), 3 * D, (long)T * 3 * D, vT, b, T, Tpad, D, st);
+        bool fused = false;
+        if (pf_flash) {
+            FlashP f; memset(&f, 0, sizeof(f));
+            f.q = (const bf16_t*)qkv; f.k = (const bf16_t*)qkv + D; f.vt = (const bf16_t*)vT; f.o = (bf16_t*)att;
+            f.q_sb = f.k_sb = (long)T * 3 * D; f.q_st = f.k_st = 3 * D; f.vt_sb = (long)D * Tpad; f.vt_ld = Tpad; f.o_sb = (long)T * D; f.o_st = D;
+            f.Tq = f.Tk = T; f.H = Hn; f.scale = 0.125f; f.mode = 1; f.mask = (const unsigned char*)c->maskb.p;
+            fused = car_launch_flash64(&f, b, st) == 0;
+        }
+        if (!fused) {
             GemmP q = gp(qkv, 3 * D, off(qkv, (size_t)D, e), 3 * D, S, T, T, T, 64);
             q.alpha = 0.125f; q.out_f32 = 1; q.nb0 = b; q.nb1 = Hn;
             q.sA0 = (long)T * 3 * D; q.sA1 = 64; q.sW0 = (long)T * 3 * D; q.sW1 = 64; q.sC0 = (long)Hn * T * T; q.sC1 = (long)T * T;
             car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+            car_launch_softmax(mode, S, T, P, Tpad, (long)b * Hn * T, T, 1, (const unsigned char*)c->maskb.p, T, Hn, st);
         }
-        car_launch_softmax(mode, S, T, P, Tpad, (long)b * Hn * T, T, 1, (const unsigned char*)c->maskb.p, T, Hn, st);
-        car_launch_transpose_pad(mode, off(qkv, (size_t)2 * D, e), 3 * D, (long)T * 3 * D, vT, b, T, Tpad, D, st);
-        {
+        if (!fused) {
             GemmP q = gp(P, Tpad, vT, Tpad, att, D, T, 64, Tpad);
             q.nb0 = b; q.nb1 = Hn;
             q.sA0 = (long)Hn * T * Tpad; q.sA1 = (long)T * Tpad; q.sW0 = (long)D * Tpad; q.sW1 = (long)64 * Tpad; q.sC0 = (long)T * D; q.sC1 = 64;
@@ -1466,6 +1500,7 @@ extern "C" int car_t5_encode(car_ctx* c, const int64_t* input_ids, const int64_t
     NEED(c, c->t5_in, o_st + 2 * (size_t)n_tok * 8);
     int* ids32 = (int*)c->t5_in.p; unsigned char* mk = (unsigned char*)c->t5_in.p + o_mk; long long* stage = (long long*)((char*)c->t5_in.p + o_st);
     int CH = B; if (CH > 64) CH = 64;
+    const bool flash = use_flash(c, hd);
     const long rows_max = (long)CH * T;
     NEED(c, c->ws[1], (size_t)n_tok * D * e);                 // h (all rows: gathered up front)
     NEED(c, c->ws[2], (size_t)rows_max * D * e);              // xn
@@ -1503,15 +1538,23 @@ extern "C" int car_t5_encode(car_ctx* c, const int64_t* input_ids, const int64_t
                 GemmP q = gp(xn, D, Wp(c, L + "0.SelfAttention." + names[k] + ".weight"), D, dst[k], inner, (int)rows, inner, D);
                 car_launch_gemm(mode, AMODE_PLAIN, &q, st);
             }
-            {   // scores[b,h] = Q K^T (scaling 1.0)
+            car_launch_transpose_pad(mode, vp, inner, (long)T * inner, vT, nb, T, Tpad, inner, st);
+            bool fused = false;
+            if (flash) {
+                FlashP f; memset(&f, 0, sizeof(f));
+                f.q = (const bf16_t*)qp; f.k = (const bf16_t*)kp; f.vt = (const bf16_t*)vT; f.o = (bf16_t*)ctx;
+                f.q_sb = f.k_sb = f.o_sb = (long)T * inner; f.q_st = f.k_st = f.o_st = inner; f.vt_sb = (long)inner * Tpad; f.vt_ld = Tpad;
+                f.Tq = f.Tk = T; f.H = nh; f.scale = 1.0f; f.mode = 2; f.mask = mk + (size_t)b0 * T; f.bias = bias;
+                fused = car_launch_flash64(&f, nb, st) == 0;
+            }
+            if (!fused) {   // scores[b,h] = Q K^T (scaling 1.0)
                 GemmP q = gp(qp, inner, kp, inner, S, T, T, T, hd);
                 q.out_f32 = 1; q.nb0 = nb; q.nb1 = nh;
                 q.sA0 = (long)T * inner; q.sA1 = hd; q.sW0 = (long)T * inner; q.sW1 = hd; q.sC0 = (long)nh * T * T; q.sC1 = (long)T * T;
                 car_launch_gemm(mode, AMODE_PLAIN, &q, st);
+                car_launch_t5_softmax(mode, S, T, P, Tpad, (long)nb * nh * T, T, bias, mk + (size_t)b0 * T, T, nh, st);
             }
-            car_launch_t5_softmax(mode, S, T, P, Tpad, (long)nb * nh * T, T, bias, mk + (size_t)b0 * T, T, nh, st);
-            car_launch_transpose_pad(mode, vp, inner, (long)T * inner, vT, nb, T, Tpad, inner, st);
-            {   // ctx[b, t, h*hd + d] = P[b,h] @ V[b,h]
+            if (!fused) {   // ctx[b, t, h*hd + d] = P[b,h] @ V[b,h]
                 GemmP q = gp(P, Tpad, vT, Tpad, ctx, inner, T, hd, Tpad);
                 q.nb0 = nb; q.nb1 = nh;
                 q.sA0 = (long)nh * T * Tpad; q.sA1 = (long)T * Tpad; q.sW0 = (long)inner * Tpad; q.sW1 = (long)hd * Tpad; q.sC0 = (long)T * inner; q.sC1 = hd;
