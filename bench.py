@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--image-h", type=int, default=0, help="non-square (MR) height; token grid = H/16 x W/16, rope grid = max side (sample_t2i_MR.py:73-78)")
     ap.add_argument("--image-w", type=int, default=0)
-    ap.add_argument("--weights-fp8", action="store_true", help="BASELINE config 5: e4m3 decode weights")
+    ap.add_argument("--weights-fp8", action="store_true", help="e4m3 decode weights, weight-only (widened to bf16 in registers, bf16 MFMA)")
+    ap.add_argument("--fp8-mfma", action="store_true", help="BASELINE config 5: e4m3 decode weights x e4m3 activations on the fp8 MFMA (W8A8)")
     ap.add_argument("--condition-type", default="canny", help="'canny'/'seg' -> nearest resize, anything else -> bicubic (dinov2_adapter.py:19-23)")
     ap.add_argument("--adapter-size", default="small", choices=["small", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,7 +59,9 @@ def parse():
     elif a.config == 4:
         a.cfg_scale, a.batch, a.image_h, a.image_w = 4.0, 1, 768, 512
     elif a.config == 5:
-        a.batch, a.weights_fp8, a.condition_type, a.adapter_size = 8, True, "hed", "base"
+        a.batch, a.fp8_mfma, a.condition_type, a.adapter_size = 8, True, "hed", "base"
+    if a.fp8_mfma:
+        a.weights_fp8 = True
     return a
 
 
@@ -150,7 +153,7 @@ def main():
     log("synthesising weights")
     gsd, vsd = synth.path_state_dicts(cfg, seed=0)          # identical on every rank (seeded CPU generator)
     # Two contexts, as the reference keeps two modules (gpt_model, vq_model).
-    eng = Engine(cfg, args.precision, device=dev, weights_fp8=args.weights_fp8)
+    eng = Engine(cfg, args.precision, device=dev, weights_fp8=("mfma" if args.fp8_mfma else args.weights_fp8))
     vq_eng = Engine(cfg, args.precision, device=dev)
     log("loading weights into the HIP contexts")
     eng.load_state_dict(gsd, finalize=True)
@@ -257,7 +260,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"LlamaGen-{args.model.upper()} t2i + DINOv2-{args.adapter_size} {args.condition_type} control, {Hh}x{Ww} ({n_new} tokens), "
-                                   f"{'fp8 (e4m3) decode weights, ' if args.weights_fp8 else ''}"
+                                   f"{'fp8 (e4m3) decode weights x e4m3 activations on the fp8 MFMA, ' if args.fp8_mfma else ('fp8 (e4m3) decode weights (weight-only), ' if args.weights_fp8 else '')}"
                                    f"cfg_scale={args.cfg_scale}, greedy, {args.batch} images/GPU/step; stages A-H "
                                    "(control encoder, generate, VQ decode) all inside the timed region",
                        "images_per_gpu": args.batch, "global_batch": G, "cfg_scale": args.cfg_scale,

@@ -44,6 +44,7 @@ struct GemmDP {
     const bf16_t* X;      // packed [ceil(M/16)][K/32][64][8]
     int M, N, K;
     int w_nt;             // stream W with the non-temporal policy (single M tile: each byte is used once)
+    int f8_mfma;          // F8 kernels: 1 = quantise the X fragments to e4m3 in registers and multiply on v_mfma_f32_16x16x32_fp8_fp8 (W8A8), 0 = widen W to bf16
     const float* wscale;  // F8 kernels: per-output-row fp32 scale of the e4m3 weight image [N/16][K/64][64][16 B] (engine.hip upload_packed_fp8)
     // EPI_RESID: h[m][n] (row-major, ld = N) updated in place
     bf16_t* h;
@@ -76,8 +77,22 @@ __device__ inline bf16x8 fp8x8_to_bf16x8_(unsigned lo, unsigned hi) {
     return *(bf16x8*)&r;
 }
 
+// 8 bf16 (one X fragment) -> 8 OCP e4m3fn bytes, round-to-nearest-even, clamped to +-448 (unit activation scale)
+__device__ inline long bf16x8_to_fp8x8_(const u32x4 x) {
+    int lo = 0, hi = 0;
+#define CL(v) __builtin_amdgcn_fmed3f((v), -448.0f, 448.0f)
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(CL(__uint_as_float(x[0] << 16)), CL(__uint_as_float(x[0] & 0xffff0000u)), lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(CL(__uint_as_float(x[1] << 16)), CL(__uint_as_float(x[1] & 0xffff0000u)), lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(CL(__uint_as_float(x[2] << 16)), CL(__uint_as_float(x[2] & 0xffff0000u)), hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(CL(__uint_as_float(x[3] << 16)), CL(__uint_as_float(x[3] & 0xffff0000u)), hi, true);
+#undef CL
+    return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
 // F8 = 1: weight-only e4m3 (BASELINE config 5; the reference has no fp8 path): one 16-byte weight load carries the fragments
 // of TWO k-blocks, widened to bf16 in registers; the per-row scale multiplies the folded fp32 sum in the epilogue.
+// F8 = 2: W8A8 — the same weight image, but the X fragments are quantised to e4m3 in registers (once per fragment, reused by the I
+// weight row-blocks) and the product runs on the fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8): no widening of W at all.
 // NORM = 1 (J = 1, M <= 16: the latency-bound small-batch regime): the RMSNorm that produces X runs in the prologue of every
 // workgroup (16 rows x 2.5 KB from L2) while the first weight stages are already in flight, and X fragments come from LDS —
 // one dependent kernel per linear fewer than "norm kernel -> GEMM".
@@ -132,9 +147,21 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 #pragma unroll
             for (int u = 0; u < XPU; ++u) x[u] = *(const u32x4*)(xl + (ku * XPU + u) * 32);
         }
+        long x8[J][2];
+        if (F8 == 2) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) { x8[j][0] = bf16x8_to_fp8x8_(x[j * XPU]); x8[j][1] = bf16x8_to_fp8x8_(x[j * XPU + XPU - 1]); }
+        }
 #pragma unroll
         for (int i = 0; i < I; ++i) {
-            if (F8) {
+            if (F8 == 2) {
+                const long a0 = (long)(((unsigned long long)w[i][1] << 32) | w[i][0]), a1 = (long)(((unsigned long long)w[i][3] << 32) | w[i][2]);
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, x8[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, x8[j][1], acc[i][j], 0, 0, 0);
+                }
+            } else if (F8) {
                 const bf16x8 a0 = fp8x8_to_bf16x8_(w[i][0], w[i][1]), a1 = fp8x8_to_bf16x8_(w[i][2], w[i][3]);
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
@@ -316,12 +343,12 @@ extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStr
     if (epi == EPI_SWIGLU && cfg < 200) return -1;       // the (a, c) pair needs two adjacent row-blocks in one tile
     if (p->N % (16 * (cfg / 100)) || p->K % 32) return -1;
     if (p->wscale && p->K % 64) return -1;
-    const bool f8 = p->wscale != nullptr;
+    const int f8 = p->wscale ? (p->f8_mfma ? 2 : 1) : 0;
     if (p->nw) {                                         // fused-norm variant: one m-block
         if (p->M > 16 || (cfg / 10) % 10 != 1 || epi == EPI_RESID || p->K > 2048) return -1;
         switch (cfg) {
-#define CASE(I) case I * 100 + 10: if (f8) launch_gemm_ij<I, 1, 4, 1, 1>(*p, epi, st); else launch_gemm_ij<I, 1, 4, 0, 1>(*p, epi, st); break; \
-                case I * 100 + 11: if (f8) launch_gemm_ij<I, 1, 8, 1, 1>(*p, epi, st); else launch_gemm_ij<I, 1, 8, 0, 1>(*p, epi, st); break;
+#define CASE(I) case I * 100 + 10: if (f8 == 2) launch_gemm_ij<I, 1, 4, 2, 1>(*p, epi, st); else if (f8) launch_gemm_ij<I, 1, 4, 1, 1>(*p, epi, st); else launch_gemm_ij<I, 1, 4, 0, 1>(*p, epi, st); break; \
+                case I * 100 + 11: if (f8 == 2) launch_gemm_ij<I, 1, 8, 2, 1>(*p, epi, st); else if (f8) launch_gemm_ij<I, 1, 8, 1, 1>(*p, epi, st); else launch_gemm_ij<I, 1, 8, 0, 1>(*p, epi, st); break;
             CASE(1) CASE(2) CASE(4)
 #undef CASE
             default: return -1;
@@ -329,8 +356,8 @@ extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStr
         return 0;
     }
     switch (cfg) {
-#define CASE(I, J) case I * 100 + J * 10: if (f8) launch_gemm_ij<I, J, 4, 1, 0>(*p, epi, st); else launch_gemm_ij<I, J, 4, 0, 0>(*p, epi, st); break; \
-                   case I * 100 + J * 10 + 1: if (f8) launch_gemm_ij<I, J, 8, 1, 0>(*p, epi, st); else launch_gemm_ij<I, J, 8, 0, 0>(*p, epi, st); break;
+#define CASE(I, J) case I * 100 + J * 10: if (f8 == 2) launch_gemm_ij<I, J, 4, 2, 0>(*p, epi, st); else if (f8) launch_gemm_ij<I, J, 4, 1, 0>(*p, epi, st); else launch_gemm_ij<I, J, 4, 0, 0>(*p, epi, st); break; \
+                   case I * 100 + J * 10 + 1: if (f8 == 2) launch_gemm_ij<I, J, 8, 2, 0>(*p, epi, st); else if (f8) launch_gemm_ij<I, J, 8, 1, 0>(*p, epi, st); else launch_gemm_ij<I, J, 8, 0, 0>(*p, epi, st); break;
         CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
 #undef CASE
         default: return -1;

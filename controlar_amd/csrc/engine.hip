@@ -40,7 +40,7 @@ struct AttnP {
 // decode2.hip
 enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 struct GemmDP {
-    const bf16_t* W; const bf16_t* X; int M, N, K; int w_nt; const float* wscale;
+    const bf16_t* W; const bf16_t* X; int M, N, K; int w_nt; int f8_mfma; const float* wscale;
     bf16_t* h; bf16_t* outp; float* outf;
     bf16_t* qout; bf16_t* kc; bf16_t* vc; const float* rope; const int* pos; int H, SA, dim;
     const bf16_t* nh_in; const bf16_t* nemb; const int* nidx; bf16_t* nh_out; const bf16_t* nw; const bf16_t* nctrl;
@@ -956,7 +956,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     auto gemm = [&](const std::string& wname, const bf16_t* X, int N, int K, int epi, GemmDP gp_) {
         GemmDP p = gp_;
         p.W = (const bf16_t*)Wp(c, wname + (f8 ? "#pk8" : "#pk")); p.X = X; p.M = b; p.N = N; p.K = K;
-        p.wscale = f8 ? (const float*)Wp(c, wname + "#sc") : nullptr;
+        p.wscale = f8 ? (const float*)Wp(c, wname + "#sc") : nullptr; p.f8_mfma = g.decode_weight_fp8 == 2;
         const int cfg = car_pick_gemm_cfg(b, N, K, epi);
         const int J = (cfg / 10) % 10, Mb = (b + 15) / 16;
         p.w_nt = (Mb + J - 1) / J == 1;

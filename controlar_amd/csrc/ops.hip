@@ -11,6 +11,12 @@
         else hipLaunchKernelGGL((KERNEL<float>), grid, block, 0, st, __VA_ARGS__);            \
     } while (0)
 
+__device__ __forceinline__ void ld8bf_ops(const bf16_t* p, float (&v)[8]) {
+    const uint4 u = *(const uint4*)p; const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+
 // ------------------------------------------------------------------ dtype conversion (inputs arrive as f32 or bf16)
 template <typename T>
 __global__ void convert_kernel(const void* src, int src_dtype, void* dst, long n) {
@@ -327,6 +333,29 @@ __global__ void gn_apply_kernel(const void* x_, const float* stats, const void* 
         ET<T>::st((T*)y_ + i, v);
     }
 }
+// bf16, C a power of two <= 2048: a thread owns 8 fixed channels (its group statistics, gamma and beta stay in registers) and walks
+// pixels with 16-byte loads / stores; same fp32 op order as gn_apply_kernel ((x - mean) * rstd * gamma + beta, one rounding, swish).
+__global__ __launch_bounds__(256) void gn_apply_vec_kernel(const bf16_t* __restrict__ x_, const float* __restrict__ stats, const bf16_t* __restrict__ gamma,
+                                                           const bf16_t* __restrict__ beta, bf16_t* __restrict__ y_, int HW, int C, int G, int swish, int ppb) {
+    const int b = blockIdx.y, cpv = C >> 3, nslot = 256 / cpv, v = threadIdx.x % cpv, slot = threadIdx.x / cpv, cpg = C / G;
+    float mu[8], rs[8], gm[8], bt[8];
+    ld8bf_ops(gamma + v * 8, gm); ld8bf_ops(beta + v * 8, bt);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float* stt = stats + ((long)b * G + (v * 8 + e) / cpg) * 2; mu[e] = stt[0]; rs[e] = stt[1]; }
+    const bf16_t* x = x_ + (long)b * HW * C + v * 8; bf16_t* y = y_ + (long)b * HW * C + v * 8;
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    for (int p = p0 + slot; p < p1; p += nslot) {
+        float xv[8]; ld8bf_ops(x + (long)p * C, xv);
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            float a = bf2f(f2bf((xv[e] - mu[e]) * rs[e] * gm[e] + bt[e])), c = bf2f(f2bf((xv[e + 1] - mu[e + 1]) * rs[e + 1] * gm[e + 1] + bt[e + 1]));
+            if (swish) { a = a / (1.0f + __expf(-a)); c = c / (1.0f + __expf(-c)); }
+            o[e >> 1] = (unsigned)f2bf(a) | ((unsigned)f2bf(c) << 16);
+        }
+        *(uint4*)(y + (long)p * C) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
 // bf16, C a power of two <= 2048: 16-byte loads (8 channels per lane), the pixels of a chunk dealt round-robin to 256 / (C/8)
 // lane slots, slot sums folded in fixed order through LDS.  Same output as gn_partial_kernel (per-chunk per-channel sum, sum-sq).
 __global__ __launch_bounds__(256) void gn_partial_vec_kernel(const bf16_t* __restrict__ x_, float* __restrict__ part, int HW, int C) {
@@ -372,6 +401,12 @@ extern "C" void car_launch_groupnorm(int mode, const void* x, const void* gamma,
     else if (mode == 1) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
     else hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, st, part, stats, nchunk, C, G, HW, eps);
+    if (mode == 1 && C >= 8 && C <= 2048 && (C & (C - 1)) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && !getenv("CAR_GN_SCALAR")) {
+        const int nslot = 256 / (C >> 3); int ppb = nslot * 8; if (ppb > HW) ppb = HW;
+        hipLaunchKernelGGL(gn_apply_vec_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)gamma, (const bf16_t*)beta,
+                           (bf16_t*)y, HW, C, G, swish, ppb);
+        return;
+    }
     long total = (long)B * HW * C; int g = (int)((total + 255) / 256); if (g > 8192) g = 8192;
     LAUNCH_T(mode, gn_apply_kernel, dim3(g), dim3(256), st, x, stats, gamma, beta, y, B, HW, C, G, swish);
 }

@@ -57,7 +57,8 @@ class Engine:
         cc.model_type = 1 if g.model_type == "c2i" else 0
         cc.num_classes = g.num_classes
         cc.stream_priority = int(stream_priority)
-        cc.decode_weight_fp8 = int(bool(weights_fp8))          # BASELINE config 5; bf16 mode only
+        # BASELINE config 5; bf16 mode only.  True / 1 = weight-only e4m3 (bf16 MFMA); 'mfma' / 2 = W8A8 on the fp8 MFMA
+        cc.decode_weight_fp8 = 2 if weights_fp8 in ("mfma", 2) else int(bool(weights_fp8))
         cc.codebook_size, cc.codebook_dim, cc.z_channels, cc.vq_ch = q.codebook_size, q.codebook_embed_dim, q.z_channels, q.ch
         cc.vq_num_res_blocks, cc.vq_n_mult, cc.gn_eps = q.num_res_blocks, len(q.ch_mult), q.gn_eps
         for i, m in enumerate(q.ch_mult):

@@ -65,7 +65,9 @@ typedef struct car_config {
     int32_t stream_priority;  /* priority of the context's internal HIP streams: 0 default, 1 lowest, 2 highest (overlapping a
                                  compute-bound context with a latency-bound one on the same GPU) */
     int32_t decode_weight_fp8; /* CAR_BF16 only: the five decode linears (wqkv, wo, w1|w3, w2, output) stream OCP e4m3fn weights with
-                                  per-output-row fp32 scales (BASELINE config 5).  The reference has no fp8 path: tolerance-graded only. */
+                                  per-output-row fp32 scales (BASELINE config 5).  1 = weight-only: bytes widened to bf16 in registers, bf16 MFMA.
+                                  2 = W8A8: activations quantised to e4m3 (unit scale, clamped to +-448) in registers and multiplied on the
+                                  fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8).  The reference has no fp8 path: tolerance-graded only. */
     int32_t reserved[3];
 } car_config;
 

@@ -237,6 +237,14 @@ class GPTState:
         self.mask = torch.tril(torch.ones(s_max, s_max, dtype=torch.bool)).unsqueeze(0).repeat(b, 1, 1)
         self.ctrl: Optional[List[Tensor]] = None
         self.control_strength = 1.0
+        # model of the library's W8A8 decode mode (car_config.decode_weight_fp8 = 2; NOT a reference feature): the inputs of the five
+        # decode linears are rounded to OCP e4m3 (unit scale, clamped to +-448) on single-token steps; the prefill stays as is
+        self.act_fp8_decode = False
+
+    def lin(self, x: Tensor, name: str) -> Tensor:
+        if self.act_fp8_decode and x.shape[1] == 1:
+            x = x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
+        return F.linear(x, self.w(name))
 
     def w(self, name):
         return self.sd[name].to(self.dtype)
@@ -266,7 +274,7 @@ def transformer_forward(st: GPTState, h: Tensor, input_pos: Tensor) -> Tensor:
                 h = h + st.control_strength * c[:, input_pos - g.cls_token_num + 1]
         p = f"layers.{i}."
         x = rms_norm(h, st.w(p + "attention_norm.weight"), g.norm_eps)
-        qkv = F.linear(x, st.w(p + "attention.wqkv.weight"))
+        qkv = st.lin(x, p + "attention.wqkv.weight")
         xq, xk, xv = qkv.split([D, D, D], dim=-1)
         xq = apply_rope(xq.view(b, s, g.n_head, g.head_dim), fc).transpose(1, 2)
         xk = apply_rope(xk.view(b, s, g.n_head, g.head_dim), fc).transpose(1, 2)
@@ -277,13 +285,12 @@ def transformer_forward(st: GPTState, h: Tensor, input_pos: Tensor) -> Tensor:
         sc = sc.masked_fill(~mask, float("-inf"))
         att = (torch.softmax(sc, dim=-1) @ st.v[i].float()).to(h.dtype)
         att = att.transpose(1, 2).reshape(b, s, D)
-        h = h + F.linear(att, st.w(p + "attention.wo.weight"))
+        h = h + st.lin(att, p + "attention.wo.weight")
         x = rms_norm(h, st.w(p + "ffn_norm.weight"), g.norm_eps)
-        ff = F.linear(F.silu(F.linear(x, st.w(p + "feed_forward.w1.weight"))) * F.linear(x, st.w(p + "feed_forward.w3.weight")),
-                      st.w(p + "feed_forward.w2.weight"))
+        ff = st.lin(F.silu(st.lin(x, p + "feed_forward.w1.weight")) * st.lin(x, p + "feed_forward.w3.weight"), p + "feed_forward.w2.weight")
         h = h + ff
     h = rms_norm(h, st.w("norm.weight"), g.norm_eps)
-    return F.linear(h, st.w("output.weight")).float()
+    return st.lin(h, "output.weight").float()
 
 
 def top_k_top_p_filtering(logits: Tensor, top_k: int = 0, top_p: float = 1.0) -> Tensor:
@@ -318,7 +325,7 @@ def generate(sd, cfg, cond: Tensor, max_new_tokens: int, emb_masks: Optional[Ten
              cfg_scale: float = 1.0, cfg_interval: int = -1, condition: Optional[Tensor] = None,
              control_strength: float = 1.0, dtype=torch.float32, forced_tokens: Optional[Tensor] = None,
              return_logits: bool = False, temperature=1.0, top_k=0, top_p=1.0, sample_logits=False,
-             generator=None, return_stages: bool = False):
+             generator=None, return_stages: bool = False, act_fp8_decode: bool = False):
     """reference: generate.py:134-204 (t2i branch) incl. prefill :85-94, decode_one_token :97-110,
     decode_n_tokens :113-131.  ``forced_tokens`` [B,N] switches to the teacher-forced protocol of
     SURVEY.md Appendix G (token fed back = forced token; logits still recorded)."""
@@ -348,6 +355,7 @@ def generate(sd, cfg, cond: Tensor, max_new_tokens: int, emb_masks: Optional[Ten
     b = cond.shape[0]
     s_max = ((T + max_new_tokens + 7) // 8) * 8                                           # gpt_t2i.py:395
     st = GPTState(sd, cfg, b, s_max, dtype)
+    st.act_fp8_decode = act_fp8_decode
     if emb_masks is not None:
         fold_pad_mask(st, torch.cat([emb_masks, emb_masks]) if use_cfg else emb_masks, T)
     # ---- prefill (gpt_t2i.py:433-442): text embed + control-token cache

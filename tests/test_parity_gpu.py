@@ -391,6 +391,37 @@ def test_fp8_weight_decode_config5():
     eng.close()
 
 
+def test_fp8_mfma_w8a8_decode():
+    """car_config.decode_weight_fp8 = 2: e4m3 weights x e4m3 activations on v_mfma_f32_16x16x32_fp8_fp8 (north_star "MFMA bf16/fp8",
+    BASELINE config 5 "fp8 weights on CDNA4 fp8 MFMA").  No reference counterpart: the kernel is graded against the oracle running
+    the SAME arithmetic model (dequantised weights, inputs of the five decode linears rounded to e4m3 on single-token steps,
+    oracle/controlar_oracle.py GPTState.lin), teacher-forced; the cost of the activation rounding itself is reported vs the
+    weight-only model and bounded loosely."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    from oracle import controlar_oracle as O
+    cfg = C.tiny_t2i(64, "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    B, H, W, n_new = 8, 128, 128, 32
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    qsd = _quantize_like_library(gsd, cfg)
+    toks_q, logits_w = O.generate(qsd, cfg, emb, n_new, mask, cfg_scale=1.0, condition=img, return_logits=True)
+    _, logits_a = O.generate(qsd, cfg, emb, n_new, mask, cfg_scale=1.0, condition=img, forced_tokens=toks_q, return_logits=True, act_fp8_decode=True)
+    for bsz in (B, 2):       # 8 rows: plain kernels; 2 rows: the fused-norm (NORM) variants
+        eng = Engine(cfg, "bf16", weights_fp8="mfma"); eng.load_state_dict(gsd); eng.finalize()
+        eng.encode_control(img[:bsz].cuda())
+        toks, logits = eng.generate(emb[:bsz].cuda(), n_new, mask[:bsz].cuda(), cfg_scale=1.0, forced_tokens=toks_q[:bsz], return_logits=True)
+        d = (logits.cpu() - logits_a[:bsz]).abs()
+        dw = (logits.cpu() - logits_w[:bsz]).abs()
+        print(f"W8A8 b={bsz}: vs same-model oracle max {float(d.max()):.3f} mean {float(d.mean()):.4f}; vs weight-only model max {float(dw.max()):.3f} mean {float(dw.mean()):.4f}")
+        # the e4m3 grid is coarse (3 mantissa bits): a bf16-vs-fp32 difference of the activation before rounding can flip an e4m3
+        # code, so the same-model tolerance is wider than the bf16 one
+        assert d.mean() <= 0.15 and d.max() <= 1.5, (float(d.max()), float(d.mean()))
+        assert dw.mean() <= 0.5
+        eng.close()
+
+
 @pytest.mark.parametrize("name,mk,hw", [("vq_encode_tiny", "tiny", 128), ("vq_encode_vq16_64x64", "vq16", 64)])
 def test_vq_encode_tokens(name, mk, hw):
     """VQModel.encode: encoder + quant_conv + quantizer arg-min.  Exact mode reproduces the reference's

@@ -1,5 +1,5 @@
 """GPU probe: decode-step time vs batch / chain count for the XL model (weights loaded once).  Not a test.
-usage: decode_probe.py xl 256,128 1024 1,2,4 [cfg_scale]"""
+usage: decode_probe.py xl 256,128 1024 1,2,4 [cfg_scale] [fp8|fp8mfma]"""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ batches = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "2,8,16,32,64"
 n_new = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 chains = [x for x in (sys.argv[4] if len(sys.argv) > 4 else "").split(",") if x] or [None]
 cfg_scale = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
-fp8 = len(sys.argv) > 6 and sys.argv[6] == "fp8"
+fp8 = {"fp8": True, "fp8mfma": "mfma"}.get(sys.argv[6], False) if len(sys.argv) > 6 else False   # fp8 = weight-only e4m3, fp8mfma = W8A8 on the fp8 MFMA
 cfg = C.xl_t2i(1024) if model == "xl" else C.b_t2i(1024)
 t0 = time.time()
 gsd, _ = synth.path_state_dicts(cfg, 0)
