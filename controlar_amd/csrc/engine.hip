@@ -1364,6 +1364,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
                 capturing = true; step_fn(); capturing = false;
                 if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) { graph_ok = false; (void)hipGetLastError(); }
             }
+            // (per-node priorities were tried — attention low, linears high: hipGraphKernelNodeSetAttribute(hipKernelNodeAttributePriority) is
+            //  rejected for every kernel node by HIP 7.2, profiles/r02_small_batch.txt)
             if (graph_ok && hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0) != hipSuccess) { graph_ok = false; c->gexec = nullptr; (void)hipGetLastError(); }
             if (graph) (void)hipGraphDestroy(graph);
             if (graph_ok) c->gkey = key;
