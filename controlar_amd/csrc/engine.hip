@@ -1146,8 +1146,11 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     NEED(c, c->ws[1], (size_t)rowsP * D * e);                                 // h (prefill)
     NEED(c, c->ws[2], (size_t)rowsP * D * e);                                 // xn
     NEED(c, c->ws[3], (size_t)rowsP * 3 * D * e);                             // qkv
-    NEED(c, c->ws[4], (size_t)b * Hn * T * T * 4);                            // S
-    NEED(c, c->ws[5], (size_t)b * Hn * T * Tpad * e);                         // P
+    const bool pf_flash = use_flash(c, 64);                                   // fused prefill attention: no score / probability tensors
+    if (!pf_flash) {
+        NEED(c, c->ws[4], (size_t)b * Hn * T * T * 4);                        // S
+        NEED(c, c->ws[5], (size_t)b * Hn * T * Tpad * e);                     // P
+    }
     NEED(c, c->ws[6], (size_t)b * D * Tpad * e);                              // V^T
     NEED(c, c->ws[7], (size_t)rowsP * (mode == CAR_BF16 ? Fh : 3 * Fh) * e);  // ffn mid (+ interleaved w13 out in exact mode)
     NEED(c, c->ws[8], (size_t)rowsP * D * e);                                 // attention out
@@ -1218,7 +1221,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         void* ce = c->ws[11].p;
         // scratch for the MLP hidden activations: reuse the (idle) KV area? no — use ws[7]/ws[3] sized for prefill; allocate via ws[4] if needed
         DevBuf& scratch = c->ws[4];
-        NEED(c, scratch, (size_t)Mc * D * e > (size_t)b * Hn * T * T * 4 ? (size_t)Mc * D * e : (size_t)b * Hn * T * T * 4);
+        const size_t s_bytes = pf_flash ? 0 : (size_t)b * Hn * T * T * 4;
+        NEED(c, scratch, (size_t)Mc * D * e > s_bytes ? (size_t)Mc * D * e : s_bytes);
         S = (float*)c->ws[4].p;
         mlp_tanh(c, c->ctrl_in.p, D, 0, 1, Mc, D, "condition_mlp.cap_proj.", scratch.p, ce, D, st);
         for (int k = 0; k < 3; ++k) for (int gi = 0; gi < NG; ++gi) {
@@ -1229,7 +1233,6 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         }
     }
     // ---- E. prefill over the T prefix rows (gpt_t2i.py:446-470)
-    const bool pf_flash = use_flash(c, 64);
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
         {

@@ -2,8 +2,8 @@
 as concurrent chains of M >= 96 rows through dec_gemm / dec_attn2 (controlar_amd/csrc/decode2.hip) over S_max = 1144 caches,
 and decodes 512x512 images in batch chunks — none of which the B = 1 / tiny-graph cases reach.
 
-  * XL, bf16, B = 192 (two chains of 96), 1024 tokens, teacher-forced on the reference's fp32 tokens: the golden image sits in
-    row 0 (chain 0) and row 100 (chain 1); both must stay within the tolerance calibrated on the reference's own bf16 path
+  * XL, bf16, B = 512 (two chains of 256: the bench shape) and B = 192 (two chains of 96), 1024 tokens, teacher-forced on the
+    reference's fp32 tokens: the golden image sits in row 0 (chain 0) and in a row of chain 1; both must stay within the tolerance calibrated on the reference's own bf16 path
     (tests/golden/xl_canny_512_cfg1_refbf16.npz x 1.5) and must equal each other bit for bit (same arithmetic, other chain).
   * XL + DINOv2-base, depth (bicubic), cfg 4, B = 64 (BASELINE config 3: one chain of 128 rows) against oracle steps.
   * the real VQ-16 decoder at 32x32 tokens -> 512x512 against pixels minted by the reference, in a batch that spans chunks.
@@ -20,7 +20,10 @@ from tests.cases import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def test_xl_two_chains_teacher_forced_at_bench_shape():
+@pytest.mark.parametrize("B,twin", [(512, 300), (192, 100)])
+def test_xl_two_chains_teacher_forced_at_bench_shape(B, twin):
+    """B = 512: the headline bench shape (two chains of 256 rows, 16 m-blocks per GEMM tile row, 108 GB KV cache);
+    B = 192: chains of 96 rows (ragged 6 m-block tiles)."""
     from controlar_amd import config as C, synth
     from controlar_amd.engine import Engine
     gold = dict(np.load(os.path.join(GOLDEN, "xl_canny_512_cfg1.npz")))
@@ -28,7 +31,7 @@ def test_xl_two_chains_teacher_forced_at_bench_shape():
     _, H, W, seed, _ = [int(x) for x in gold["meta"]]
     cfg = C.xl_t2i(1024, "small", "canny")
     gsd, _ = synth.path_state_dicts(cfg, seed=seed)
-    B, n_new, twin = 192, 1024, 100
+    n_new = 1024
     img = synth.canny_like_control(B, H, W).to(torch.bfloat16)            # row 0 = the golden image (seed 1234 + 0)
     emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
     img[twin], emb[twin], mask[twin] = img[0], emb[0], mask[0]
