@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step (512 sequences = 108 GB of bf16 KV cache in two chains of 256: sized for the 288 GB of one MI355X)")
+    ap.add_argument("--batch", type=int, default=768, help="images per GPU per step (768 sequences = 163 GB of bf16 KV cache in two chains of 384: sized for the 288 GB of one MI355X; measured plateau, profiles/r02_decode_batch_sweep.txt)")
     ap.add_argument("--cfg-scale", type=float, default=1.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--model", default="xl", choices=["xl", "b", "tiny"])

@@ -2,7 +2,7 @@
 as concurrent chains of M >= 96 rows through dec_gemm / dec_attn2 (controlar_amd/csrc/decode2.hip) over S_max = 1144 caches,
 and decodes 512x512 images in batch chunks — none of which the B = 1 / tiny-graph cases reach.
 
-  * XL, bf16, B = 512 (two chains of 256: the bench shape) and B = 192 (two chains of 96), 1024 tokens, teacher-forced on the
+  * XL, bf16, B = 768 (two chains of 384: the bench shape) and B = 192 (two chains of 96), 1024 tokens, teacher-forced on the
     reference's fp32 tokens: the golden image sits in row 0 (chain 0) and in a row of chain 1; both must stay within the tolerance calibrated on the reference's own bf16 path
     (tests/golden/xl_canny_512_cfg1_refbf16.npz x 1.5) and must equal each other bit for bit (same arithmetic, other chain).
   * XL + DINOv2-base, depth (bicubic), cfg 4, B = 64 (BASELINE config 3: one chain of 128 rows) against oracle steps.
@@ -20,9 +20,9 @@ from tests.cases import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,twin", [(512, 300), (192, 100)])
+@pytest.mark.parametrize("B,twin", [(768, 500), (192, 100)])
 def test_xl_two_chains_teacher_forced_at_bench_shape(B, twin):
-    """B = 512: the headline bench shape (two chains of 256 rows, 16 m-blocks per GEMM tile row, 108 GB KV cache);
+    """B = 768: the headline bench shape (two chains of 384 rows = 24 m-blocks, 163 GB KV cache, 52 GB of recorded logits);
     B = 192: chains of 96 rows (ragged 6 m-block tiles)."""
     from controlar_amd import config as C, synth
     from controlar_amd.engine import Engine

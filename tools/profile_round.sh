@@ -7,13 +7,13 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_trace /tmp/pmc_f /tmp/pmc_w
 ( timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/r02_trace_bench.json 2> $OUT/r02_trace_bench.err )
 T=$(find /tmp/prof_trace -name '*kernel_trace.csv' | head -1)
-[ -n "$T" ] && python $ROOT/tools/trace_summary.py $T > $OUT/r02_bench_b256_trace_summary.txt && python $ROOT/tools/trace_summary.py $T 0.5 > $OUT/r02_bench_b256_trace_summary_decode_half.txt
-S=$(find /tmp/prof_trace -name '*kernel_stats.csv' | head -1); [ -n "$S" ] && cp $S $OUT/r02_bench_b256_kernel_stats.csv
-( timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python $ROOT/tools/pmc_workload.py 256 514 509 > $OUT/r02_pmc_f.log 2>&1 )
-( timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python $ROOT/tools/pmc_workload.py 256 514 509 > $OUT/r02_pmc_w.log 2>&1 )
+[ -n "$T" ] && python $ROOT/tools/trace_summary.py $T > $OUT/r02_bench_b768_trace_summary.txt && python $ROOT/tools/trace_summary.py $T 0.5 > $OUT/r02_bench_b768_trace_summary_decode_half.txt
+S=$(find /tmp/prof_trace -name '*kernel_stats.csv' | head -1); [ -n "$S" ] && cp $S $OUT/r02_bench_b768_kernel_stats.csv
+( timeout 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python $ROOT/tools/pmc_workload.py 768 514 509 > $OUT/r02_pmc_f.log 2>&1 )
+( timeout 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python $ROOT/tools/pmc_workload.py 768 514 509 > $OUT/r02_pmc_w.log 2>&1 )
 F=$(find /tmp/pmc_f -name '*counter_collection.csv' | head -1); W=$(find /tmp/pmc_w -name '*counter_collection.csv' | head -1)
 if [ -n "$F" ] && [ -n "$W" ]; then
-  python $ROOT/tools/pmc_decode.py $F $W 4 256 $OUT/pmc_decode_step.json > $OUT/r02_pmc_decode_b256.txt 2>&1
+  python $ROOT/tools/pmc_decode.py $F $W 4 768 $OUT/pmc_decode_step.json > $OUT/r02_pmc_decode_b768.txt 2>&1
   python $ROOT/tools/pmc_summary.py $F > $OUT/r02_pmc_FETCH_SIZE_all_kernels.txt; python $ROOT/tools/pmc_summary.py $W > $OUT/r02_pmc_WRITE_SIZE_all_kernels.txt
 fi
-tail -2 $OUT/r02_pmc_f.log $OUT/r02_pmc_w.log; cat $OUT/r02_trace_bench.json; head -30 $OUT/r02_bench_b256_trace_summary_decode_half.txt; tail -5 $OUT/r02_pmc_decode_b256.txt
+tail -2 $OUT/r02_pmc_f.log $OUT/r02_pmc_w.log; cat $OUT/r02_trace_bench.json; head -30 $OUT/r02_bench_b768_trace_summary_decode_half.txt; tail -5 $OUT/r02_pmc_decode_b768.txt
