@@ -43,7 +43,7 @@ struct GemmDP {
     const bf16_t* W;      // packed [N/16][K/32][64][8]
     const bf16_t* X;      // packed [ceil(M/16)][K/32][64][8]
     int M, N, K;
-    int w_nt;             // stream W with the non-temporal policy (single M tile: each byte is used once)
+    int w_nt;             // bit 0: stream W with the non-temporal policy (single M tile: each byte is used once); bit 1: raise the wave priority (s_setprio 3)
     int f8_mfma;          // F8 kernels: 1 = quantise the X fragments to e4m3 in registers and multiply on v_mfma_f32_16x16x32_fp8_fp8 (W8A8), 0 = widen W to bf16
     const float* wscale;  // F8 kernels: per-output-row fp32 scale of the e4m3 weight image [N/16][K/64][64][16 B] (engine.hip upload_packed_fp8)
     // EPI_RESID: h[m][n] (row-major, ld = N) updated in place
@@ -105,6 +105,9 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     float* red = NORM ? red_all + (16 * xs_ld) / 2 : red_all;
     constexpr int XPU = F8 ? 2 : 1;                                    // X chunks (k-blocks) per weight load unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // raised wave priority: when this kernel shares a CU with the other decode chain's attention waves (HBM-bound, thousands of them),
+    // the instruction arbiter serves these few latency-bound waves first
+    if (p.w_nt & 2) __builtin_amdgcn_s_setprio(3);
     const int nkb = p.K >> 5, nku = nkb / XPU, Mb = (p.M + 15) >> 4;
     const int MT = (Mb + J - 1) / J;
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of tiles —
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 #pragma unroll
         for (int i = 0; i < I; ++i) {
             const u32x4* a = wp + ((long)i * nku + ku) * 64;
-            w[i] = p.w_nt ? __builtin_nontemporal_load(a) : *a;
+            w[i] = (p.w_nt & 1) ? __builtin_nontemporal_load(a) : *a;
         }
         if (!NORM) {
 #pragma unroll
@@ -616,7 +619,7 @@ extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const
 // branch; xn is written in the XP layout that dec_gemm consumes.
 struct Norm2P {
     const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
-    const bf16_t* ctrl; const int* pos; int add; int T; int n_tok; float cs;
+    const bf16_t* ctrl; const int* pos; int add /* bit 0: add the control token, bit 1: raised wave priority */; int T; int n_tok; float cs;
     int D; float eps;
 };
 // one WAVE per row (4 rows per workgroup): a decode-step row is 2.5 KB, so the kernel is pure latency — no LDS, no barrier,
@@ -628,7 +631,8 @@ __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
     const int lane = threadIdx.x & 63;
     const int D = p.D, ng = D >> 2;
     const bf16_t* src = p.idx ? p.emb + (long)p.idx[r] * D : p.h_in + r * D;
-    const bf16_t* add = p.add ? p.ctrl + (r * p.n_tok + (*p.pos - p.T + 1)) * D : nullptr;
+    if (p.add & 2) __builtin_amdgcn_s_setprio(3);        // see dec_gemm_kernel
+    const bf16_t* add = (p.add & 1) ? p.ctrl + (r * p.n_tok + (*p.pos - p.T + 1)) * D : nullptr;
     float val[NQ][4];
     float ss = 0.f;
 #pragma unroll

@@ -129,7 +129,7 @@ struct Wt { void* p = nullptr; std::vector<int64_t> shape; int64_t numel = 0; si
 struct car_ctx {
     car_config cfg; int mode = 0; size_t esz = 4;
     std::string err;
-    hipStream_t streamx[7] = {}; hipEvent_t ev_fork = nullptr, ev_joinx[7] = {};
+    hipStream_t streamx[7] = {}; hipEvent_t ev_fork = nullptr, ev_joinx[7] = {}, ev_phase[7] = {};
     hipStream_t stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
     std::unordered_map<std::string, Wt> w;            // packed weights by (reference) name, element type T unless noted
     std::unordered_map<std::string, std::vector<float>> host_keep;   // host fp32 copies needed later (pos-emb, w1/w3 halves in exact mode)
@@ -161,7 +161,8 @@ struct car_ctx {
     DevBuf t5_bias; int t5_bias_T = 0;   // position bias fp32 [heads][T][T] of the last sequence length
     int st_b = 0, st_T = 0, st_nsteps = 0, st_has_mask = 0; double st_wbytes = 0; const int* st_jmin = nullptr;   // inputs of the lazy decode_algo_bytes
     // decode graph
-    hipGraphExec_t gexec = nullptr; std::string gkey;
+    hipGraphExec_t gexec = nullptr; std::string gkey;          // the captured decode step(s): `graph_steps` consecutive tokens per replay
+    hipGraphExec_t gexec1 = nullptr; std::string gkey1;        // single-step graph for the remainder when graph_steps > 1
     car_stats stats;
     int n_dec_kernels = 0;
 };
@@ -210,7 +211,8 @@ extern "C" int car_create(car_ctx** out, const car_config* cfg) {
         g_create_err = "car_create: stream/event creation failed"; delete c; return -1;
     }
     for (int i = 0; i < 7; ++i)
-        if (hipStreamCreateWithPriority(&c->streamx[i], hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&c->ev_joinx[i], hipEventDisableTiming) != hipSuccess) {
+        if (hipStreamCreateWithPriority(&c->streamx[i], hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&c->ev_joinx[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_phase[i], hipEventDisableTiming) != hipSuccess) {
             g_create_err = "car_create: stream/event creation failed"; delete c; return -1;
         }
     // 2-D RoPE table (gpt_t2i.py:506-519): rows [0,T) zero, then grid*grid rows of (cos,sin) x 32 pairs
@@ -241,6 +243,7 @@ extern "C" void car_destroy(car_ctx* c) {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
     if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+    if (c->gexec1) (void)hipGraphExecDestroy(c->gexec1);
     for (auto& kv : c->w) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : c->pos_cache) (void)hipFree(kv.second);
     for (auto& kv : c->resize_cache) { (void)hipFree(kv.second.iy); (void)hipFree(kv.second.ix); if (kv.second.wy) (void)hipFree(kv.second.wy); if (kv.second.wx) (void)hipFree(kv.second.wx); }
@@ -249,7 +252,7 @@ extern "C" void car_destroy(car_ctx* c) {
     c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release(); c->canny_map.release(); c->t5_in.release(); c->t5_bias.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
     (void)hipStreamDestroy(c->stream);
-    for (int i = 0; i < 7; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); }
+    for (int i = 0; i < 7; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); (void)hipEventDestroy(c->ev_phase[i]); }
     (void)hipEventDestroy(c->ev_fork);
     delete c;
 }
@@ -943,8 +946,13 @@ struct Grp { int b0, bg, nsplit, attn_variant, attn_lds_pad; int *pos, *step; Fa
 
 // bf16 fast path (decode2.hip): 7 kernels per layer — norm -> wqkv(+RoPE, KV write) -> attention -> wo(+residual) ->
 // norm -> w1|w3(+SwiGLU) -> w2(+residual); every linear streams the weights once for all rows of the chain.
+// `phase_ev` / `phase_dst` (multi-chain capture): right after this chain's FIRST wqkv the event is recorded and `phase_dst` (the next
+// chain's stream) is made to wait for it — the next chain enters the step half a layer late, so that its latency-bound linears run
+// under this chain's HBM-bound attention and vice versa (chains forked at the same node run in lockstep: both do their linears at the
+// same time, then both their attention, and nothing is hidden).  `prio`: the linears / norms raise their wave priority (s_setprio).
 static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& gr, int b_total, int SA, int n_tok, bool use_ctrl,
-                                    float cs, const unsigned char* maskb, const int* jmin, hipStream_t st) {
+                                    float cs, const unsigned char* maskb, const int* jmin, hipStream_t st,
+                                    hipEvent_t phase_ev = nullptr, hipStream_t phase_dst = nullptr, int prio = 0) {
     const car_config& g = c->cfg;
     const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, li = g.n_layer / 3, V = g.vocab_size, T = g.cls_token_num;
     const int b = gr.bg, b0 = gr.b0, nsplit = gr.nsplit;
@@ -959,7 +967,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         p.wscale = f8 ? (const float*)Wp(c, wname + "#sc") : nullptr; p.f8_mfma = g.decode_weight_fp8 == 2;
         const int cfg = car_pick_gemm_cfg(b, N, K, epi);
         const int J = (cfg / 10) % 10, Mb = (b + 15) / 16;
-        p.w_nt = (Mb + J - 1) / J == 1;
+        p.w_nt = ((Mb + J - 1) / J == 1 ? 1 : 0) | (prio ? 2 : 0);      // bit 0: non-temporal weight stream, bit 1: raised wave priority
         if (car_launch_dec_gemm_cfg(&p, epi, cfg, st)) bad_cfg = cfg;
         ++nk;
     };
@@ -984,10 +992,10 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         bf16_t* kc = (bf16_t*)c->kv.p + (size_t)(2 * l) * kv_layer + kv_off; bf16_t* vc = (bf16_t*)c->kv.p + (size_t)(2 * l + 1) * kv_layer + kv_off;
         if (!fuse_norm) {   // [token gather at layer 0] (+ control add at layers 0, n/3, 2n/3) -> h ; attention_norm -> xn (packed)
             Norm2P np; memset(&np, 0, sizeof(np));
-            np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps; np.add = prio ? 2 : 0;
             if (l == 0) { np.emb = (const bf16_t*)Wp(c, "tok_embeddings.weight"); np.idx = sb.cur + b0; np.h_out = h; }
             if (use_ctrl && l % li == 0 && l / li < 3) {
-                np.add = 1; np.ctrl = (const bf16_t*)c->ctrl[l / li].p + (size_t)b0 * n_tok * D; np.pos = gr.pos; np.T = T; np.n_tok = n_tok; np.cs = cs; np.h_out = h;
+                np.add |= 1; np.ctrl = (const bf16_t*)c->ctrl[l / li].p + (size_t)b0 * n_tok * D; np.pos = gr.pos; np.T = T; np.n_tok = n_tok; np.cs = cs; np.h_out = h;
             }
             car_launch_rmsnorm2(&np, b, st); ++nk;
         }
@@ -996,6 +1004,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             if (fuse_norm) { norm_fields(q, L + "attention_norm.weight", l, true); }
             gemm(L + "attention.wqkv.weight", fb.xn, 3 * D, D, EPI_QKV, q);
             if (fuse_norm && q.nh_out) hc = q.nh_out;
+            if (l == 0 && phase_ev) { (void)hipEventRecord(phase_ev, st); (void)hipStreamWaitEvent(phase_dst, phase_ev, 0); }
         }
         {
             Attn2P ap; memset(&ap, 0, sizeof(ap));
@@ -1006,7 +1015,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         { GemmDP q = z; q.h = hc; gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
         if (!fuse_norm) {
             Norm2P np; memset(&np, 0, sizeof(np));
-            np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps; np.add = prio ? 2 : 0;
             car_launch_rmsnorm2(&np, b, st); ++nk;
         }
         { GemmDP q = z; q.outp = fb.mid; if (fuse_norm) norm_fields(q, L + "ffn_norm.weight", l, false); gemm(L + "feed_forward.w13.weight", fb.xn, 2 * Fh, D, EPI_SWIGLU, q); }
@@ -1014,7 +1023,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     }
     if (!fuse_norm) {
         Norm2P np; memset(&np, 0, sizeof(np));
-        np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps;
+        np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps; np.add = prio ? 2 : 0;
         car_launch_rmsnorm2(&np, b, st); ++nk;
     }
     { GemmDP q = z; q.outf = fb.logits; if (fuse_norm) norm_fields(q, "norm.weight", g.n_layer, false); gemm("output.weight", fb.xn, V, D, EPI_LOGITS, q); }
@@ -1311,6 +1320,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             gr.b0 = mult * img0[gi]; gr.bg = mult * (img0[gi + 1] - img0[gi]);
             const int bg = gr.bg; const size_t M16 = rup((size_t)bg, 16);
             gr.nsplit = 1; { const int wg = bg * Hn; while (wg * gr.nsplit < 1024 && gr.nsplit < 16) gr.nsplit *= 2; }
+            { const char* ev = getenv("CAR_ATTN_NSPLIT"); if (ev) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) gr.nsplit = v; } }   // A/B knob: shorter attention workgroups
             // attention variant (decode2.hip; profiles/r02_kbench_*): 4 waves per (sequence, head) from 128 sequences up, 2 below
             gr.attn_variant = (gr.nsplit == 1 && bg < 128) ? 20 : 40; gr.attn_lds_pad = 0;
             { const char* ev = getenv("CAR_ATTN_VARIANT"); if (ev) gr.attn_variant = atoi(ev); ev = getenv("CAR_ATTN_LDS_PAD"); if (ev) gr.attn_lds_pad = atoi(ev); }
@@ -1331,54 +1341,80 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     }
     const unsigned char* fmask = emb_mask ? (const unsigned char*)c->maskb.p : nullptr;      // no text-pad mask: nothing to test per position
     const int* fjmin = emb_mask ? jmin : nullptr;
+    // ---- decode-loop schedule knobs (fast mode).  Defaults from the MI355X sweep of tools/overlap_sweep.py (profiles/).
+    //   phase offset : with >= 2 chains, chain g+1 enters the step right after chain g's first wqkv (see enqueue_decode_step_fast)
+    //   graph steps  : consecutive tokens captured per graph replay — the chains free-run across them (one fork / join and one phase
+    //                  offset per `gsteps` tokens instead of per token); the remainder runs on a single-step graph
+    //   linear prio  : s_setprio on the linears / norms
+    int phase = 0, gsteps = 1, lin_prio = 0;
+    if (fast) {
+        const char* ev = getenv("CAR_PHASE_OFFSET"); if (ev) phase = atoi(ev) != 0;
+        ev = getenv("CAR_GRAPH_STEPS"); if (ev) { const int v = atoi(ev); if (v >= 1 && v <= 64) gsteps = v; }
+        ev = getenv("CAR_LINEAR_PRIO"); if (ev) lin_prio = atoi(ev) != 0;
+    }
+    if (NG < 2) phase = 0;
     bool capturing = false;
     int step_rc = 0;
-    auto step_fn = [&]() {
-        if (!fast) { enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st); return; }
-        if (NG >= 2 && capturing) {      // fork NG-1 extra branches inside the capture
-            (void)hipEventRecord(c->ev_fork, st);
-            for (int gi = 1; gi < NG; ++gi) (void)hipStreamWaitEvent(c->streamx[gi - 1], c->ev_fork, 0);
-            step_rc |= enqueue_decode_step_fast(c, sb, grp[0], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, st);
-            for (int gi = 1; gi < NG; ++gi) {
-                step_rc |= enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, c->streamx[gi - 1]);
-                (void)hipEventRecord(c->ev_joinx[gi - 1], c->streamx[gi - 1]); (void)hipStreamWaitEvent(st, c->ev_joinx[gi - 1], 0);
+    auto enqueue_steps = [&](int k) {      // k consecutive decode steps of every chain
+        if (!fast) { for (int s = 0; s < k; ++s) enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st); return; }
+        if (NG >= 2 && capturing) {         // the chains are parallel branches of the captured graph
+            if (!phase) {
+                (void)hipEventRecord(c->ev_fork, st);
+                for (int gi = 1; gi < NG; ++gi) (void)hipStreamWaitEvent(c->streamx[gi - 1], c->ev_fork, 0);
+            }
+            for (int gi = 0; gi < NG; ++gi) {
+                hipStream_t sg = gi == 0 ? st : c->streamx[gi - 1];
+                for (int s = 0; s < k; ++s) {
+                    const bool hand = phase && s == 0 && gi + 1 < NG;      // chain gi+1's stream joins the capture through this event
+                    step_rc |= enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, sg,
+                                                        hand ? c->ev_phase[gi] : nullptr, hand ? c->streamx[gi] : nullptr, lin_prio);
+                }
+                if (gi > 0) { (void)hipEventRecord(c->ev_joinx[gi - 1], sg); (void)hipStreamWaitEvent(st, c->ev_joinx[gi - 1], 0); }
             }
         } else {
-            for (int gi = 0; gi < NG; ++gi) step_rc |= enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, st);
+            for (int s = 0; s < k; ++s)
+                for (int gi = 0; gi < NG; ++gi) step_rc |= enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, st, nullptr, nullptr, lin_prio);
         }
-        c->n_dec_kernels *= NG;
+        c->n_dec_kernels *= NG;             // kernel nodes of ONE step over all chains
     };
     if (nsteps > 0) {
-        char keyb[512];
+        char keyb[640];
         // every scalar and pointer that the captured kernels bake in (n_new: the sampler's row stride and per-chain offsets)
         snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%d|%d|%p|%p", b, B, S_max, n_new, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
                  (const void*)forced_tokens, (void*)logits_out);
-        { char kb2[200]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad);
+        { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
+                                  grp[0].nsplit, phase, lin_prio);
           strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
-        bool graph_ok = true;
-        if (getenv("CAR_NO_GRAPH")) { /* skip capture */ }
-        else if (!c->gexec || c->gkey != key) {
-            if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        const bool no_graph = getenv("CAR_NO_GRAPH") != nullptr;      // profiling aid: eager launches (PMC collection cannot follow graph replays)
+        // capture `k` steps into `ex` unless the cached exec already holds exactly this configuration
+        auto get_exec = [&](hipGraphExec_t& ex, std::string& exkey, int k) -> bool {
+            const std::string kk = key + "|k" + std::to_string(k);
+            if (ex && exkey == kk) return true;
+            if (ex) { (void)hipGraphExecDestroy(ex); ex = nullptr; exkey.clear(); }
             hipGraph_t graph = nullptr;
-            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_ok = false; (void)hipGetLastError(); }
-            if (graph_ok) {
-                capturing = true; step_fn(); capturing = false;
-                if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) { graph_ok = false; (void)hipGetLastError(); }
-            }
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
+            capturing = true; enqueue_steps(k); capturing = false;
+            bool ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
+            if (!ok) (void)hipGetLastError();
             // (per-node priorities were tried — attention low, linears high: hipGraphKernelNodeSetAttribute(hipKernelNodeAttributePriority) is
             //  rejected for every kernel node by HIP 7.2, profiles/r02_small_batch.txt)
-            if (graph_ok && hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0) != hipSuccess) { graph_ok = false; c->gexec = nullptr; (void)hipGetLastError(); }
+            if (ok && hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) != hipSuccess) { ok = false; ex = nullptr; (void)hipGetLastError(); }
             if (graph) (void)hipGraphDestroy(graph);
-            if (graph_ok) c->gkey = key;
-        }
-        if (getenv("CAR_NO_GRAPH")) graph_ok = false;      // profiling aid: eager launches (PMC collection cannot follow graph replays)
-        if (graph_ok) {
-            for (int i = 0; i < nsteps; ++i) HIPCHK(c, hipGraphLaunch(c->gexec, st));
+            if (ok) exkey = kk;
+            return ok;
+        };
+        const int nrep = nsteps / gsteps, nrem = nsteps % gsteps;
+        bool graph_ok = !no_graph;
+        if (graph_ok && nrep > 0) graph_ok = get_exec(c->gexec, c->gkey, gsteps);
+        if (graph_ok && nrem > 0) graph_ok = get_exec(gsteps > 1 ? c->gexec1 : c->gexec, gsteps > 1 ? c->gkey1 : c->gkey, 1);
+        if (graph_ok && !step_rc) {
+            for (int i = 0; i < nrep; ++i) HIPCHK(c, hipGraphLaunch(c->gexec, st));
+            for (int i = 0; i < nrem; ++i) HIPCHK(c, hipGraphLaunch(gsteps > 1 ? c->gexec1 : c->gexec, st));
             c->stats.graph_used = 1;
-        } else {
-            for (int i = 0; i < nsteps; ++i) step_fn();
+        } else if (!step_rc) {
+            for (int i = 0; i < nsteps; ++i) enqueue_steps(1);
         }
     }
     if (step_rc) { fence_out(c, caller); return -1; }        // c->err was set by the step builder

@@ -447,3 +447,32 @@ def test_vq_encode_tokens(name, mk, hw):
         else:
             assert (toks == gold["tokens"]).mean() >= 0.6, (toks == gold["tokens"]).mean()
         eng.close()
+
+
+@pytest.mark.parametrize("chains", ["2", "3"])
+def test_chain_schedule_knobs_do_not_change_tokens(chains, monkeypatch):
+    """The decode-loop schedule (phase offset between the chains, several tokens per captured graph with a single-step remainder,
+    raised wave priority of the linears) only moves launches around: free-running tokens must equal the lockstep schedule's bit for bit."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    cfg = C.tiny_t2i(64, "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    B, H, W, n_new = 48, 128, 128, 24                       # 23 decode steps = 4 x 5 + 3
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    monkeypatch.setenv("CAR_CHAINS", chains)
+    monkeypatch.setenv("CAR_PHASE_OFFSET", "0"); monkeypatch.setenv("CAR_GRAPH_STEPS", "1"); monkeypatch.setenv("CAR_LINEAR_PRIO", "0")
+    want = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=1.0).cpu()
+    assert eng.stats()["graph_used"]
+    for env in ({"CAR_PHASE_OFFSET": "1"}, {"CAR_PHASE_OFFSET": "1", "CAR_GRAPH_STEPS": "5"}, {"CAR_GRAPH_STEPS": "23"},
+                {"CAR_PHASE_OFFSET": "1", "CAR_GRAPH_STEPS": "64", "CAR_LINEAR_PRIO": "1"}):
+        for k, v in {"CAR_PHASE_OFFSET": "0", "CAR_GRAPH_STEPS": "1", "CAR_LINEAR_PRIO": "0", **env}.items():
+            monkeypatch.setenv(k, v)
+        got = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=1.0).cpu()
+        assert eng.stats()["graph_used"], env
+        assert torch.equal(got, want), env
+        again = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=1.0).cpu()      # replay of the cached graphs
+        assert torch.equal(again, want), env
+    eng.close()

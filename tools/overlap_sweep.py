@@ -1,0 +1,85 @@
+"""GPU probe: schedule knobs of the multi-chain decode loop at the bench shape (weights loaded once).  Not a test.
+
+The chains of a decode step are parallel branches of one captured graph.  Forked at the same node they run in LOCKSTEP (both do
+their linears together, then both their attention): nothing hides under the HBM-bound attention.  CAR_PHASE_OFFSET=1 lets chain
+g+1 enter the step right after chain g's first wqkv, so one chain's linears run under the other's attention.  This probe measures
+that and the neighbouring knobs, and checks that every variant with the same chain count produces the SAME tokens (the arithmetic
+is untouched: only the launch schedule changes).
+
+usage: overlap_sweep.py [B=768] [n_new=1024] [quick]
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from controlar_amd import config as C, synth  # noqa: E402
+from controlar_amd.engine import Engine  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 768
+n_new = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+quick = len(sys.argv) > 3 and sys.argv[3] == "quick"
+KNOBS = ["CAR_CHAINS", "CAR_SINGLE_CHAIN", "CAR_PHASE_OFFSET", "CAR_GRAPH_STEPS", "CAR_LINEAR_PRIO", "CAR_ATTN_VARIANT", "CAR_ATTN_NSPLIT", "CAR_ATTN_LDS_PAD"]
+
+cfg = C.xl_t2i(1024)
+t0 = time.time()
+gsd, _ = synth.path_state_dicts(cfg, 0)
+eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+print("load %.1fs" % (time.time() - t0), flush=True)
+
+
+def run(Bn, env, reps=0):
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    img = synth.canny_like_control(Bn, 512, 512).to(torch.bfloat16).cuda()
+    emb, mask = synth.text_embeddings(Bn, 120, 2048)
+    emb = emb.to(torch.bfloat16).cuda(); mask = mask.cuda()
+    eng.encode_control(img)
+    best, toks = None, None
+    for _ in range(reps + 1):                     # one pass is representative: the graph is captured on the host while the GPU is still in the prefill
+        toks = eng.generate(emb, n_new, mask, cfg_scale=1.0); torch.cuda.synchronize()
+        st = eng.stats()
+        ms = st["decode_ms"] / st["decode_steps"]
+        best = ms if best is None else min(best, ms)
+    gbs = st["decode_algo_bytes"] / st["decode_steps"] / (best * 1e-3) / 1e9
+    return best, gbs, st, toks.cpu()
+
+
+def sweep(Bn, variants):
+    base = {}
+    for name, env in variants:
+        try:
+            ms, gbs, st, toks = run(Bn, env)
+        except Exception as e:                    # a knob the library rejects must not end the sweep
+            print(json.dumps(dict(B=Bn, variant=name, error=str(e)[:200])), flush=True)
+            continue
+        ng = env.get("CAR_CHAINS", "1" if "CAR_SINGLE_CHAIN" in env else "default")
+        ref = base.setdefault(ng, toks)           # first variant of each chain count is the reference
+        print(json.dumps(dict(B=Bn, variant=name, env=env, ms_per_step=round(ms, 4), algo_GBps=round(gbs, 1), frac=round(gbs / 8000, 4),
+                              kernels=st["decode_kernels_per_step"], graph=st["graph_used"],
+                              tokens_equal_to_first_of_same_chain_count=bool(torch.equal(toks, ref)),
+                              token_agreement=round(float((toks == ref).float().mean()), 4))), flush=True)
+
+
+P = {"CAR_PHASE_OFFSET": "1"}
+big = [("lockstep (round-2 default)", {}),
+       ("phase", dict(P)),
+       ("phase+graph8", dict(P, CAR_GRAPH_STEPS="8")),
+       ("phase+prio", dict(P, CAR_LINEAR_PRIO="1")),
+       ("phase+attn20", dict(P, CAR_ATTN_VARIANT="20")),
+       ("phase+nsplit2", dict(P, CAR_ATTN_NSPLIT="2")),
+       ("3 chains lockstep", {"CAR_CHAINS": "3"}),
+       ("3 chains phase", dict(P, CAR_CHAINS="3")),
+       ("4 chains phase", dict(P, CAR_CHAINS="4"))]
+if quick:
+    big = big[:4]
+sweep(B, big)
+if not quick:
+    # smaller batches: does the phase offset move the batch size from which two chains pay?
+    for Bs in (256, 64):
+        sweep(Bs, [("1 chain", {"CAR_SINGLE_CHAIN": "1"}), ("2 chains lockstep", {"CAR_CHAINS": "2"}), ("2 chains phase", dict(P, CAR_CHAINS="2")),
+                   ("2 chains phase+prio", dict(P, CAR_CHAINS="2", CAR_LINEAR_PRIO="1"))])
+eng.close()
