@@ -398,6 +398,7 @@ struct Attn2P {
     bf16_t* out;                // nsplit == 1: attention output, XP-packed [ceil(b/16)][dim/32][64][8] if out_packed else [b][dim]
     float* part;                // nsplit > 1: [b][H][nsplit][66] (m, l, o[64])
     int H, SA, T, dim, nsplit, out_packed;
+    int n_seq, pgrid;           // persistent form (nsplit == 1): n_seq > 0 sequences, a 1-D grid of pgrid workgroups walks the n_seq*H items
 };
 
 // NWAVE waves share one (sequence, head): wave w of split s takes 32-position blocks blk0 + s*NWAVE + w, stride nsplit*NWAVE.
@@ -405,9 +406,17 @@ struct Attn2P {
 template <int NWAVE, int PF>
 __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     __shared__ float red[NWAVE][66];
-    const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
+    const int split = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
     const int pos = *p.pos;
+    // Persistent form (n_seq > 0): every workgroup of the grid is resident from the start and walks items blockIdx.x, +gridDim.x, ...
+    // A grid of thousands of (sequence, head) workgroups keeps the dispatcher busy for the whole kernel, and the OTHER decode chain's
+    // short linears (a second branch of the captured graph) only get workgroup slots in its tail; a resident grid leaves them the
+    // wave slots and registers it does not use.  Same arithmetic per item: results are bit-identical to the one-item-per-workgroup form.
+    const bool persist = p.n_seq > 0;
+    const int n_items = persist ? p.n_seq * p.H : 1;
+    for (int it = persist ? (int)blockIdx.x : 0; it < n_items; it += gridDim.x) {
+    const int h = persist ? it % p.H : (int)blockIdx.x, b = persist ? it / p.H : (int)blockIdx.y;
     const long sbase = ((long)b * p.H + h) * p.SA * 64;
     const u32x4* Kp = (const u32x4*)(p.kc + sbase) + lane;
     const u32x4* Vp = (const u32x4*)(p.vc + sbase) + lane;
@@ -523,6 +532,8 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
             pt[2 + tid] = O;
         }
     }
+    if (persist) __syncthreads();       // `red` is reused by the next item
+    }
 }
 
 // text-pad mask rows for the decode batch: out[r][t] = emb_mask[row_img[r]][t] != 0 (all ones without a mask); generate.py:184-193
@@ -572,7 +583,10 @@ __global__ __launch_bounds__(64) void dec_attn2_combine_kernel(const float* part
 // lds_pad: bytes of (unused) dynamic LDS requested per workgroup — an occupancy cap: with two decode chains in flight the
 // attention of one chain must leave registers and wave slots on every CU for the other chain's GEMM workgroups
 extern "C" void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, int lds_pad, hipStream_t st) {
-    const dim3 g(p->H, b, p->nsplit);
+    const bool persist = p->n_seq > 0 && p->pgrid > 0 && p->nsplit == 1;
+    Attn2P q = *p; if (!persist) { q.n_seq = 0; q.pgrid = 0; }
+    p = &q;
+    const dim3 g = persist ? dim3(q.pgrid, 1, 1) : dim3(p->H, b, p->nsplit);
     const size_t sh = (size_t)(lds_pad > 0 ? lds_pad : 0);
     switch (variant) {
         case 20: hipLaunchKernelGGL((dec_attn2_kernel<2, 0>), g, dim3(128), sh, st, *p); break;

@@ -49,6 +49,7 @@ struct GemmDP {
 struct Attn2P {
     const bf16_t* q; const bf16_t* kc; const bf16_t* vc; const int* pos; const unsigned char* mask; const int* jmin;
     bf16_t* out; float* part; int H, SA, T, dim, nsplit, out_packed;
+    int n_seq, pgrid;
 };
 struct Norm2P {
     const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
@@ -154,6 +155,7 @@ struct car_ctx {
     int h_init[16] = {};
     SampleDyn h_dyn = {};
     int dbg_skip = 0;
+    int n_cu = 256;       // compute units of the device (persistent-grid sizing)
     DevBuf rowimg;       // [b] int: image index of each row
     DevBuf canny_map;    // car_canny: uint8 [B,H,W] candidate/edge map + the "changed" flag
     car_t5_config t5 = {}; bool has_t5 = false;
@@ -199,6 +201,7 @@ extern "C" int car_create(car_ctx** out, const car_config* cfg) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "car_create: no HIP device visible (this library has no CPU fallback)"; return -1; }
     car_ctx* c = new car_ctx();
     c->cfg = *cfg; c->mode = cfg->mode; c->esz = cfg->mode == CAR_BF16 ? 2 : 4;
+    { int dev = 0, ncu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) c->n_cu = ncu; else (void)hipGetLastError(); }
     memset(&c->stats, 0, sizeof(c->stats));
     int prio_lo = 0, prio_hi = 0, prio = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // lo = numerically largest = least urgent
@@ -942,7 +945,7 @@ struct StepBufs { void *h, *xn, *qkv, *att, *mid, *mid2; float* part; float* log
 // captured step has parallel branches: one chain's HBM-bound attention overlaps the other chains' latency-bound GEMMs
 // (each chain re-streams the weights; a layer's 40 MB sits in the 256 MiB MALL between chains).
 struct FastBufs { bf16_t *xn, *att, *mid, *q; float* logits; float* attn_part; };     // per-chain scratch (XP-packed activations)
-struct Grp { int b0, bg, nsplit, attn_variant, attn_lds_pad; int *pos, *step; FastBufs fb; SampleP sp; };
+struct Grp { int b0, bg, nsplit, attn_variant, attn_lds_pad, attn_pgrid; int *pos, *step; FastBufs fb; SampleP sp; };
 
 // bf16 fast path (decode2.hip): 7 kernels per layer — norm -> wqkv(+RoPE, KV write) -> attention -> wo(+residual) ->
 // norm -> w1|w3(+SwiGLU) -> w2(+residual); every linear streams the weights once for all rows of the chain.
@@ -1010,6 +1013,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             Attn2P ap; memset(&ap, 0, sizeof(ap));
             ap.q = fb.q; ap.kc = kc; ap.vc = vc; ap.pos = gr.pos; ap.mask = maskb ? maskb + (size_t)b0 * T : nullptr; ap.jmin = jmin ? jmin + b0 : nullptr;
             ap.out = fb.att; ap.part = fb.attn_part; ap.H = Hn; ap.SA = SA; ap.T = T; ap.dim = D; ap.nsplit = nsplit; ap.out_packed = 1;
+            if (gr.attn_pgrid > 0 && nsplit == 1) { ap.n_seq = b; ap.pgrid = gr.attn_pgrid; }
             car_launch_dec_attn2_var(&ap, b, gr.attn_variant, gr.attn_lds_pad, st); nk += nsplit > 1 ? 2 : 1;
         }
         { GemmDP q = z; q.h = hc; gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
@@ -1324,6 +1328,11 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             // attention variant (decode2.hip; profiles/r02_kbench_*): 4 waves per (sequence, head) from 128 sequences up, 2 below
             gr.attn_variant = (gr.nsplit == 1 && bg < 128) ? 20 : 40; gr.attn_lds_pad = 0;
             { const char* ev = getenv("CAR_ATTN_VARIANT"); if (ev) gr.attn_variant = atoi(ev); ev = getenv("CAR_ATTN_LDS_PAD"); if (ev) gr.attn_lds_pad = atoi(ev); }
+            // persistent attention grid: R resident workgroups per CU walk the (sequence, head) items in equal shares
+            gr.attn_pgrid = 0;
+            { const char* ev = getenv("CAR_ATTN_PERSIST"); const int R = ev ? atoi(ev) : 0;
+              if (R > 0 && R <= 16 && gr.nsplit == 1) { const long items = (long)bg * Hn, cap = (long)c->n_cu * R;
+                  if (items > cap) { const long per = (items + cap - 1) / cap; gr.attn_pgrid = (int)((items + per - 1) / per); } } }
             sizes[gi][0] = M16 * D * 2; sizes[gi][1] = M16 * D * 2; sizes[gi][2] = M16 * Fh * 2; sizes[gi][3] = rup((size_t)bg * D * 2, 16);
             sizes[gi][4] = (size_t)bg * V * 4; sizes[gi][5] = rup((size_t)bg * Hn * gr.nsplit * 66 * 4, 16);
             for (int k = 0; k < 6; ++k) tot += sizes[gi][k];
@@ -1383,8 +1392,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         snprintf(keyb, sizeof(keyb), "%d|%d|%d|%d|%d|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%d|%d|%d|%p|%p", b, B, S_max, n_new, n_tok, nsplit, (int)use_control, c->kv.p, h, logits,
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
                  (const void*)forced_tokens, (void*)logits_out);
-        { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
-                                  grp[0].nsplit, phase, lin_prio);
+        { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
+                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid);
           strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
         const bool no_graph = getenv("CAR_NO_GRAPH") != nullptr;      // profiling aid: eager launches (PMC collection cannot follow graph replays)
