@@ -25,7 +25,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 n_new = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 which = sys.argv[3] if len(sys.argv) > 3 else "all"
 quick = which == "quick"
-KNOBS = ["CAR_ATTN_PERSIST", "CAR_CHAINS", "CAR_SINGLE_CHAIN", "CAR_PHASE_OFFSET", "CAR_GRAPH_STEPS", "CAR_LINEAR_PRIO", "CAR_ATTN_VARIANT", "CAR_ATTN_NSPLIT", "CAR_ATTN_LDS_PAD"]
+KNOBS = ["CAR_NO_GRAPH", "CAR_ATTN_PERSIST", "CAR_CHAINS", "CAR_SINGLE_CHAIN", "CAR_PHASE_OFFSET", "CAR_GRAPH_STEPS", "CAR_LINEAR_PRIO", "CAR_ATTN_VARIANT", "CAR_ATTN_NSPLIT", "CAR_ATTN_LDS_PAD"]
 
 cfg = C.xl_t2i(1024)
 t0 = time.time()
@@ -39,7 +39,10 @@ _inputs = {}
 
 def inputs(Bn):       # synthesised once per batch size (22 ms of host time per image)
     if Bn not in _inputs:
-        img = synth.canny_like_control(Bn, 512, 512).to(torch.bfloat16).cuda()
+        if which == "diag":       # any {-1,+1} map will do for a timing diagnosis
+            img = (torch.rand(Bn, 1, 512, 512, generator=torch.Generator().manual_seed(5)) > 0.92).to(torch.bfloat16).mul(2).sub(1).expand(Bn, 3, 512, 512).contiguous().cuda()
+        else:
+            img = synth.canny_like_control(Bn, 512, 512).to(torch.bfloat16).cuda()
         emb, mask = synth.text_embeddings(Bn, 120, 2048)
         _inputs[Bn] = (img, emb.to(torch.bfloat16).cuda(), mask.cuda())
     return _inputs[Bn]
@@ -69,7 +72,7 @@ def sweep(Bn, variants):
         except Exception as e:                    # a knob the library rejects must not end the sweep
             print(json.dumps(dict(B=Bn, variant=name, error=str(e)[:200])), flush=True)
             continue
-        ng = env.get("CAR_CHAINS", "1" if "CAR_SINGLE_CHAIN" in env else "default")
+        ng = "any" if which == "diag" else env.get("CAR_CHAINS", "1" if "CAR_SINGLE_CHAIN" in env else "default")
         ref = base.setdefault(ng, toks)           # first variant of each chain count is the reference
         print(json.dumps(dict(B=Bn, variant=name, env=env, ms_per_step=round(ms, 4), algo_GBps=round(gbs, 1), frac=round(gbs / 8000, 4),
                               kernels=st["decode_kernels_per_step"], graph=st["graph_used"],
@@ -97,6 +100,11 @@ if which == "persist":
            ("persist3+phase", dict(P, CAR_ATTN_PERSIST="3")),
            ("persist6+phase", dict(P, CAR_ATTN_PERSIST="6")),
            ("persist4 lockstep", {"CAR_ATTN_PERSIST": "4"})]
+if which == "diag":
+    # do the graph's parallel branches overlap at all?  one chain of all rows, and the two chains launched eagerly on ONE stream (strictly serial)
+    big = [("2 chains, graph branches (round-2 default)", {}),
+           ("1 chain", {"CAR_SINGLE_CHAIN": "1"}),
+           ("2 chains, eager launches on one stream", {"CAR_NO_GRAPH": "1"})]
 sweep(B, big)
 if which == "all":
     # smaller batches: does the phase offset move the batch size from which two chains pay?
