@@ -37,6 +37,7 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {          // v_cvt_pk_
     return *(const unsigned*)&r;
 }
 
+#define CAR_GEMMDP_DEFINED
 enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 
 struct GemmDP {
