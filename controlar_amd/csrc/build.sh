@@ -6,12 +6,12 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p _obj
 pids=()
-for f in gemm ops decode decode2 decode3 pack canny t5 attn engine; do
+for f in gemm ops decode decode2 pack canny t5 attn engine; do
   if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ car_common.h -nt _obj/$f.o ] || [ ../../include/controlar_hip.h -nt _obj/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o _obj/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libcontrolar_hip.so _obj/gemm.o _obj/ops.o _obj/decode.o _obj/decode2.o _obj/decode3.o _obj/pack.o _obj/canny.o _obj/t5.o _obj/attn.o _obj/engine.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libcontrolar_hip.so _obj/gemm.o _obj/ops.o _obj/decode.o _obj/decode2.o _obj/pack.o _obj/canny.o _obj/t5.o _obj/attn.o _obj/engine.o
 echo "built $(pwd)/libcontrolar_hip.so"

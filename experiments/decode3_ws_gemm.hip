@@ -1,5 +1,10 @@
-// decode3.hip — weight-stationary slab GEMM for the decode linears of a LARGE chain (M >= 96 rows).  EXPERIMENTAL: off by default
-// (engine.hip knob CAR_GEMM_WS); validated standalone by experiments/ws_check.hip, wired behind the same GemmDP / epilogues as dec_gemm.
+// experiments/decode3_ws_gemm.hip — weight-stationary slab GEMM for the decode linears of a LARGE chain (M >= 96 rows).
+// EXPERIMENT, NOT PRODUCT (not built into libcontrolar_hip.so).  Result on MI355X (profiles/r02_ws_check_half_period.txt): correct
+// against dec_gemm on all four epilogues at the first run, but SLOWER in isolation (few, long workgroups: wqkv 24-36 vs 20 us, w2 42-61 vs
+// 11 us at M = 384) and no better beside the attention — the measurement that came with it shows why no variant can be: on two streams
+// the attention of one chain (167 us, 6.3 TB/s) and the six linears of the other (82 us) take 255 us together = their serial sum.
+// A kernel that saturates HBM starves every latency-bound kernel next to it; the 2.5 ms the two-chain graph hides per step is
+// linear-beside-linear overlap (the chains run in lockstep), not linear-under-attention.
 //
 // Why (profiles/r02_small_batch.txt, "decode overlap experiments"): with two chains in flight the step time does not react to any
 // launch-schedule change — what the linears of one chain and the attention of the other share is the path that feeds the CUs.
@@ -19,7 +24,7 @@
 // Operand traffic per linear: W once (N·K·2 B) + X once per workgroup (N/(16·I) · M·K·2 B): wqkv at M = 384 with I = 4: 9.8 + 59 MB
 // against 118 MB for dec_gemm's 64 x 64 tiles; the accumulation order differs from dec_gemm (single chain instead of WAVES partial
 // sums), so results agree to fp32 round-off before the bf16 rounding points, not bit for bit.
-#include "car_common.h"
+#include "../controlar_amd/csrc/car_common.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned ws_u32x4;
 typedef __attribute__((ext_vector_type(2))) float ws_f32x2;

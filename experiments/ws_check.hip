@@ -1,9 +1,9 @@
-// experiments/ws_check.hip — standalone check + timing of the weight-stationary slab GEMM (controlar_amd/csrc/decode3.hip) against
+// experiments/ws_check.hip — standalone check + timing of the weight-stationary slab GEMM (experiments/decode3_ws_gemm.hip) against
 // the validated dec_gemm (decode2.hip), and the measurement the schedule sweeps could not make: ONE half-period of the two-chain decode
 // step (the attention of one chain beside the six linears / norms of the other, on two streams) with either GEMM.  Test infrastructure.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I controlar_amd/csrc experiments/ws_check.hip -o experiments/ws_check && experiments/ws_check
 #include "../controlar_amd/csrc/decode2.hip"
-#include "../controlar_amd/csrc/decode3.hip"
+#include "decode3_ws_gemm.hip"
 
 #include <algorithm>
 #include <cmath>
@@ -208,6 +208,31 @@ static void bench(int M) {
             CK(hipEventRecord(eB, sB)); CK(hipStreamWaitEvent(sA, eB, 0));
         });
         printf("M=%d  %s  six linears+norms alone %6.1f us | beside the attention %6.1f us per half-period (serial sum %6.1f, attention alone %6.1f)\n", M, nm, tl, tc, ta + tl, ta);
+        fflush(stdout);
+    }
+    {   // where the two-chain graph's hidden 2.5 ms per step comes from: the linears of BOTH chains side by side (lockstep)
+        const float t2 = timed([&](int it) {
+            CK(hipEventRecord(eA, sA)); CK(hipStreamWaitEvent(sB, eA, 0));
+            linears(layer(it), 0, sA); linears(layer(it + 3), 0, sB);
+            CK(hipEventRecord(eB, sB)); CK(hipStreamWaitEvent(sA, eB, 0));
+        });
+        printf("M=%d  dec_gemm: the linears+norms of TWO chains on two streams %6.1f us (one chain alone: see above)\n", M, t2);
+        // a resident attention grid (R workgroups per CU walking the items) beside the linears: does a shallower memory queue let them through?
+        for (int R : {2, 3, 4}) {
+            auto pattn = [&](int it, hipStream_t st) {
+                Attn2P a; memset(&a, 0, sizeof(a)); a.q = qa; a.pos = dPos; a.mask = dM; a.jmin = dJ; a.out = oa; a.H = H; a.SA = SA; a.T = T; a.dim = D; a.nsplit = 1; a.out_packed = 1;
+                a.kc = dKV + kvper * 2 * (it % NKV); a.vc = a.kc + kvper;
+                const long items = (long)M * H, cap = 256L * R, per = (items + cap - 1) / cap; a.n_seq = M; a.pgrid = (int)((items + per - 1) / per);
+                car_launch_dec_attn2_var(&a, M, 40, 0, st);
+            };
+            const float tp = timed([&](int it) { pattn(it, sA); });
+            const float tpc = timed([&](int it) {
+                CK(hipEventRecord(eA, sA)); CK(hipStreamWaitEvent(sB, eA, 0));
+                pattn(it, sA); linears(layer(it), 0, sB);
+                CK(hipEventRecord(eB, sB)); CK(hipStreamWaitEvent(sA, eB, 0));
+            });
+            printf("M=%d  resident attention grid R=%d: alone %6.1f us | beside the dec_gemm linears %6.1f us per half-period\n", M, R, tp, tpc);
+        }
         fflush(stdout);
     }
     // isolated per-shape times
