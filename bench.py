@@ -166,8 +166,11 @@ def main():
     T, cap = cfg.gpt.cls_token_num, cfg.gpt.caption_dim
     if rank == 0:
         # built in chunks of 64 images and cast to bf16 at once: the global batch of an 8-GPU run is 2048 images (6.4 GB in fp32)
-        mk_img = synth.canny_like_control if args.condition_type in ("canny", "seg") else synth.smooth_control
-        img = torch.cat([mk_img(min(64, G - i0), Hh, Ww, seed=1234 + i0).to(torch.bfloat16) for i0 in range(0, G, 64)])
+        if args.condition_type in ("canny", "seg"):
+            mk_img = lambda n, h, w, seed: synth.canny_like_control(n, h, w, seed=seed, dtype=torch.bfloat16)   # noqa: E731  ({-1,+1}: exact in bf16)
+        else:
+            mk_img = lambda n, h, w, seed: synth.smooth_control(n, h, w, seed=seed).to(torch.bfloat16)           # noqa: E731
+        img = torch.cat([mk_img(min(64, G - i0), Hh, Ww, seed=1234 + i0) for i0 in range(0, G, 64)])
         embs, masks = zip(*[synth.text_embeddings(min(64, G - i0), T, cap, seed=1234 + i0) for i0 in range(0, G, 64)])
         emb, mask = torch.cat([e_.to(torch.bfloat16) for e_ in embs]), torch.cat(masks)
     else:

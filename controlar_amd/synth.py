@@ -252,15 +252,17 @@ def path_state_dicts(cfg: PathConfig, seed: int = 0):
 
 
 # ----------------------------------------------------------------------------- inputs
-def canny_like_control(batch: int, H: int, W: int, seed: int = 1234, density: float = 0.08) -> torch.Tensor:
+def canny_like_control(batch: int, H: int, W: int, seed: int = 1234, density: float = 0.08, dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """Binary edge-like map in {-1,+1}, 3 identical channels, as sample_t2i.py:123-125,141
-    produces from cv2.Canny (uint8 {0,255} -> 2*(x/255-0.5))."""
-    out = []
+    produces from cv2.Canny (uint8 {0,255} -> 2*(x/255-0.5)).  One seeded generator per image (image i of any batch is the
+    same map); written straight into the output in `dtype` (both values are exact in bf16)."""
+    out = torch.empty(batch, 3, H, W, dtype=dtype)
+    one, neg = torch.tensor(1.0, dtype=dtype), torch.tensor(-1.0, dtype=dtype)
     for i in range(batch):
         g = torch.Generator().manual_seed(seed + i)
-        m = (torch.rand(H, W, generator=g) > (1.0 - density)).float()
-        out.append((2.0 * (m - 0.5))[None].repeat(3, 1, 1))
-    return torch.stack(out)
+        m = torch.rand(H, W, generator=g) > (1.0 - density)
+        out[i] = torch.where(m, one, neg)            # broadcast over the 3 channels
+    return out
 
 
 def smooth_control(batch: int, H: int, W: int, seed: int = 1234) -> torch.Tensor:
