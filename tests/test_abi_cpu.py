@@ -121,3 +121,26 @@ def test_decode_weight_fragment_packing_layout():
                 r, k0 = rb * 16 + (l & 15), kb * 32 + (l >> 4) * 8
                 assert torch.equal(got[rb, kb, l], wb[r, k0:k0 + 8]), (rb, kb, l)
     assert lib.car_debug_pack_decode_weight(C.c_void_p(w.data_ptr()), 40, K, C.c_void_p(out.ctypes.data)) != 0   # N % 16 != 0
+
+
+def test_decode_gemm_tile_choice_is_valid_for_every_model_size():
+    """car_pick_gemm_cfg (decode2.hip, host code) must hand car_launch_dec_gemm_cfg a configuration it accepts for every LlamaGen size with
+    64-wide heads (gpt_t2i.py:541-563: B, L, XL, XXL, 1B), every decode linear and every chain length — a rejected tile only shows up
+    as a run-time error of generate() on the GPU otherwise.  Mirrors the acceptance rules of car_launch_dec_gemm_cfg."""
+    import ctypes as C
+    from controlar_amd import _lib
+    from controlar_amd.config import ffn_hidden_dim
+    lib = _lib.load()
+    pick = lib.car_pick_gemm_cfg
+    pick.restype = C.c_int; pick.argtypes = [C.c_int] * 4
+    EPI_LOGITS, EPI_RESID, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3
+    for dim in (768, 1024, 1280, 1536, 2048):
+        fh, V = ffn_hidden_dim(dim), 16384
+        linears = [(3 * dim, dim, EPI_QKV), (dim, dim, EPI_RESID), (2 * fh, dim, EPI_SWIGLU), (dim, fh, EPI_RESID), (V, dim, EPI_LOGITS)]
+        for M in list(range(1, 18)) + [24, 32, 48, 64, 96, 100, 128, 144, 192, 256, 384, 512, 768, 1024]:
+            for N, K, epi in linears:
+                cfg = pick(M, N, K, epi)
+                I, J, w8 = cfg // 100, (cfg // 10) % 10, cfg % 10
+                assert I in (1, 2, 4) and J in (1, 2, 4) and w8 in (0, 1), (dim, M, N, K, epi, cfg)
+                assert N % (16 * I) == 0 and K % 32 == 0, (dim, M, N, K, epi, cfg)
+                assert epi != EPI_SWIGLU or I >= 2, (dim, M, N, K, epi, cfg)          # the (a, c) pair needs two adjacent row-blocks in one tile
