@@ -139,7 +139,7 @@ def main():
 
     from controlar_amd import config as C, synth
     from controlar_amd.engine import Engine
-    from controlar_amd.dist import broadcast_inputs, shard_slice, gather_tokens
+    from controlar_amd.dist import alloc_packed_host, broadcast_inputs, shard_slice, gather_tokens
 
     S = args.image_size
     Hh, Ww = (args.image_h or S), (args.image_w or S)
@@ -164,19 +164,22 @@ def main():
     # ---- inputs: rank 0 draws the global batch, one broadcast over RCCL/xGMI, each rank takes its shard
     G = args.batch * world
     T, cap = cfg.gpt.cls_token_num, cfg.gpt.caption_dim
+    packed = None
     if rank == 0:
-        # built in chunks of 64 images and cast to bf16 at once: the global batch of an 8-GPU run is 2048 images (6.4 GB in fp32)
-        if args.condition_type in ("canny", "seg"):
-            mk_img = lambda n, h, w, seed: synth.canny_like_control(n, h, w, seed=seed, dtype=torch.bfloat16)   # noqa: E731  ({-1,+1}: exact in bf16)
-        else:
-            mk_img = lambda n, h, w, seed: synth.smooth_control(n, h, w, seed=seed).to(torch.bfloat16)           # noqa: E731
-        img = torch.cat([mk_img(min(64, G - i0), Hh, Ww, seed=1234 + i0) for i0 in range(0, G, 64)])
-        embs, masks = zip(*[synth.text_embeddings(min(64, G - i0), T, cap, seed=1234 + i0) for i0 in range(0, G, 64)])
-        emb, mask = torch.cat([e_.to(torch.bfloat16) for e_ in embs]), torch.cat(masks)
-    else:
-        img = emb = mask = None
+        # the global batch is written chunk by chunk straight into ONE packed host buffer (6144 images = 12.7 GB at 8 GPUs x 768)
+        packed, h_img, h_emb, h_mask = alloc_packed_host(G, Hh, Ww, T, cap)
+        for i0 in range(0, G, 64):
+            n = min(64, G - i0)
+            if args.condition_type in ("canny", "seg"):
+                h_img[i0:i0 + n] = synth.canny_like_control(n, Hh, Ww, seed=1234 + i0, dtype=torch.bfloat16)      # {-1,+1}: exact in bf16
+            else:
+                h_img[i0:i0 + n] = synth.smooth_control(n, Hh, Ww, seed=1234 + i0).to(torch.bfloat16)
+            e_, m_ = synth.text_embeddings(n, T, cap, seed=1234 + i0)
+            h_emb[i0:i0 + n] = e_.to(torch.bfloat16); h_mask[i0:i0 + n] = m_
+        del h_img, h_emb, h_mask
     t_bc0 = time.perf_counter()
-    img, emb, mask = broadcast_inputs(dist, dev, rank, G, Hh, Ww, T, cap, img, emb, mask)
+    img, emb, mask = broadcast_inputs(dist, dev, rank, G, Hh, Ww, T, cap, packed=packed)
+    del packed
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t_bc0
     sl = shard_slice(G, world, rank)

@@ -18,12 +18,22 @@ def _worker(rank, world, port, G, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     H = W = 32; T, cap = 12, 64
+    import controlar_amd.dist as cdist
+    cdist.BCAST_CHUNK = 4096                    # the 56 KB payload goes out in 14 slices, as a 12.7 GB one does in 1 GiB slices
+    packed = None
+    if rank == 0:                               # bench.py's form: the global batch is written in place into one packed host buffer
+        packed, h_img, h_emb, h_mask = cdist.alloc_packed_host(G, H, W, T, cap)
+        h_img[:] = synth.canny_like_control(G, H, W, dtype=torch.bfloat16)
+        e_, m_ = synth.text_embeddings(G, T, cap); h_emb[:] = e_.to(torch.bfloat16); h_mask[:] = m_
+    img, emb, mask = broadcast_inputs(dist, torch.device("cpu"), rank, G, H, W, T, cap, packed=packed)
+    # the three-tensor form must deliver the same bytes
     if rank == 0:
-        img = synth.canny_like_control(G, H, W).to(torch.bfloat16)
-        emb, mask = synth.text_embeddings(G, T, cap); emb = emb.to(torch.bfloat16)
+        i3, (e3, m3) = synth.canny_like_control(G, H, W).to(torch.bfloat16), synth.text_embeddings(G, T, cap)
+        e3 = e3.to(torch.bfloat16)
     else:
-        img = emb = mask = None
-    img, emb, mask = broadcast_inputs(dist, torch.device("cpu"), rank, G, H, W, T, cap, img, emb, mask)
+        i3 = e3 = m3 = None
+    i3, e3, m3 = broadcast_inputs(dist, torch.device("cpu"), rank, G, H, W, T, cap, i3, e3, m3)
+    assert torch.equal(i3, img) and torch.equal(e3, emb) and torch.equal(m3, mask)
     sl = shard_slice(G, world, rank)
     # stand-in for the per-rank generate(): a deterministic function of this rank's shard only
     local = (img[sl].float().sum(dim=(1, 2, 3)).round().to(torch.int32)[:, None] +
