@@ -1,0 +1,146 @@
+// experiments/small_chain.hip — the small-batch decode regime (BASELINE configs 2, 4, 5: 2..16 rows) as a standalone, Python-free harness:
+// NL layers of the product's decode kernels (controlar_amd/csrc/decode2.hip) captured into one hipGraph exactly as engine.hip builds a
+// step for <= 4 rows, replayed and timed per layer, with variants that can be A/B'd in seconds of GPU time:
+//
+//   base      norm-fused wqkv -> split-KV attention -> combine -> wo -> norm-fused w1|w3 -> w2            (6 kernels per layer: engine.hip today)
+//   nosplit   the same with ONE attention launch (nsplit = 1, 4 waves per (row, head), prefetch form) — no combine kernel (5 per layer)
+//   w8        8-wave tile configurations for every linear (more bytes in flight per CU)
+//   prefetch  base + a side branch per layer that touches the NEXT layer's 41.6 MB of weights (a few dozen workgroups of plain loads):
+//             the linears then find their weights in the 256 MiB Infinity Cache instead of waiting on HBM.  The step streams 1 TB/s of
+//             its 8: the bandwidth for the run-ahead is free; profiles/r02_queue_check.txt shows small kernels on two queues overlap.
+//   unnorm    separate rmsnorm2 kernels instead of the fused prologue (8 kernels per layer; the > 4 rows form)
+//
+// Weights: NL distinct layers (NL x 41.6 MB > 256 MiB for NL >= 7) so that every replay streams from HBM as the real 36-layer step does.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I controlar_amd/csrc experiments/small_chain.hip -o experiments/small_chain && experiments/small_chain [rows=2] [pos=631] [prefetch workgroups=256]
+#include "../controlar_amd/csrc/decode2.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+template <typename T> static T* dalloc(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); return p; }
+
+__global__ void fill_kernel(unsigned* p, size_t n, unsigned seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) { unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        const unsigned a = (x & 0x807fu) | (((x >> 7) & 0x3f) + 64) << 7, b2 = ((x >> 16) & 0x807fu) | ((((x >> 23) & 0x3f) + 64) << 7);
+        p[i] = a | (b2 << 16); }
+}
+
+// touches `bytes` starting at `p` with plain 16-byte loads (allocating in L2 and, memory-side, in the Infinity Cache); the xor keeps the loads alive
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* p, size_t n16, unsigned* sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; const size_t st = (size_t)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    for (; i + 7 * st < n16; i += 8 * st) {          // eight independent 16-byte loads in flight per lane
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[i + u * st];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].w;
+    }
+    for (; i < n16; i += st) acc ^= p[i].x;
+    if (acc == 0x9e3779b9u) *sink = acc;              // practically never: the store only defeats dead-code elimination
+}
+
+static int g_prefetch_grid = 256;                     // 256 workgroups x 256 lanes x 8 x 16 B = 8 MB in flight
+
+struct Dims { int M, D, Fh, H, SA, T, pos; };
+struct Bufs { bf16_t *W, *kv, *h, *h2, *xn, *att, *mid, *q, *nw; float *part, *rope; int *dpos; unsigned* sink; size_t per_layer, kvper; };
+
+enum { V_BASE = 0, V_NOSPLIT = 1, V_W8 = 2, V_PREFETCH = 3, V_UNNORM = 4, V_PREFETCH_NOSPLIT = 5, NVAR = 6 };
+static const char* VNAME[NVAR] = {"base (engine.hip today, 6 kernels/layer)", "nosplit attention (5 kernels/layer)", "8-wave linears", "prefetch next layer's weights (side branch)",
+                                  "separate rmsnorm2 kernels (8 kernels/layer)", "prefetch + nosplit attention"};
+
+static void layer(const Dims& d, const Bufs& b, int l, int NL, int variant, hipStream_t st, hipStream_t side, hipEvent_t ef, hipEvent_t ej) {
+    const int D = d.D, Fh = d.Fh, M = d.M;
+    bf16_t* w = b.W + b.per_layer * (l % NL);
+    bf16_t *wqkv = w, *wo = w + (size_t)3 * D * D, *w13 = wo + (size_t)D * D, *w2 = w13 + (size_t)2 * Fh * D;
+    bf16_t* kc = b.kv + b.kvper * 2 * (l % NL); bf16_t* vc = kc + b.kvper;
+    const bool pre = variant == V_PREFETCH || variant == V_PREFETCH_NOSPLIT, nosplit = variant == V_NOSPLIT || variant == V_PREFETCH_NOSPLIT;
+    const bool fuse = variant != V_UNNORM;
+    if (pre) {       // fork: run ahead on the NEXT layer's weights while this layer's six kernels wait on each other
+        CK(hipEventRecord(ef, st)); CK(hipStreamWaitEvent(side, ef, 0));
+        const bf16_t* nxt = b.W + b.per_layer * ((l + 1) % NL);
+        hipLaunchKernelGGL(prefetch_kernel, dim3(g_prefetch_grid), dim3(256), 0, side, (const uint4*)nxt, b.per_layer * 2 / 16, b.sink);
+        CK(hipEventRecord(ej, side));
+    }
+    auto gemm = [&](const bf16_t* W, const bf16_t* X, int N, int K, int epi, GemmDP p) {
+        p.W = W; p.X = X; p.M = M; p.N = N; p.K = K;
+        int cfg = car_pick_gemm_cfg(M, N, K, epi);
+        if (variant == V_W8) cfg = (cfg / 10) * 10 + 1;
+        const int J = (cfg / 10) % 10, Mb = (M + 15) / 16; p.w_nt = (Mb + J - 1) / J == 1;
+        if (car_launch_dec_gemm_cfg(&p, epi, cfg, st)) { printf("cfg %d rejected (N=%d K=%d)\n", cfg, N, K); exit(3); }
+    };
+    GemmDP z; memset(&z, 0, sizeof(z));
+    auto norm = [&](const bf16_t* hin) { Norm2P n; memset(&n, 0, sizeof(n)); n.h_in = hin; n.xn = b.xn; n.w = b.nw; n.D = D; n.eps = 1e-5f; car_launch_rmsnorm2(&n, M, st); };
+    {   // attention_norm + wqkv (+RoPE, KV write at *pos)
+        GemmDP q = z; q.qout = b.q; q.kc = kc; q.vc = vc; q.rope = b.rope; q.pos = b.dpos; q.H = d.H; q.SA = d.SA; q.dim = D;
+        if (fuse) { q.nw = b.nw; q.neps = 1e-5f; q.nh_in = b.h; } else norm(b.h);
+        gemm(wqkv, b.xn, 3 * D, D, EPI_QKV, q);
+    }
+    {
+        Attn2P a; memset(&a, 0, sizeof(a)); a.q = b.q; a.kc = kc; a.vc = vc; a.pos = b.dpos; a.out = b.att; a.part = b.part; a.H = d.H; a.SA = d.SA; a.T = d.T; a.dim = D; a.out_packed = 1;
+        int ns = 1; while (M * d.H * ns < 1024 && ns < 16) ns *= 2;
+        a.nsplit = nosplit ? 1 : ns;
+        car_launch_dec_attn2_var(&a, M, nosplit ? 41 : 40, 0, st);
+    }
+    { GemmDP q = z; q.h = b.h; gemm(wo, b.att, D, D, EPI_RESID, q); }
+    {
+        GemmDP q = z; q.outp = b.mid;
+        if (fuse) { q.nw = b.nw; q.neps = 1e-5f; q.nh_in = b.h; q.pos = b.dpos; } else norm(b.h);
+        gemm(w13, b.xn, 2 * Fh, D, EPI_SWIGLU, q);
+    }
+    { GemmDP q = z; q.h = b.h; gemm(w2, b.mid, D, Fh, EPI_RESID, q); }
+    if (pre) CK(hipStreamWaitEvent(st, ej, 0));       // join: the side branch must end inside the captured graph
+}
+
+int main(int argc, char** argv) {
+    Dims d; d.M = argc > 1 ? atoi(argv[1]) : 2; d.D = 1280; d.Fh = 3584; d.H = 20; d.T = 120; d.pos = argc > 2 ? atoi(argv[2]) : 631; d.SA = 1152;
+    const int NL = 12, REPS = 30;
+    if (argc > 3) g_prefetch_grid = atoi(argv[3]);
+    if (d.M < 1 || d.M > 16 || d.pos < 1 || d.pos >= d.SA) { printf("rows must be 1..16, pos 1..%d\n", d.SA - 1); return 2; }
+    Bufs b; memset(&b, 0, sizeof(b));
+    b.per_layer = (size_t)(3 * d.D * d.D + d.D * d.D + 2 * d.Fh * d.D + d.D * d.Fh);
+    b.W = dalloc<bf16_t>(b.per_layer * NL);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (unsigned*)b.W, b.per_layer * NL / 2, 12345u);
+    b.kvper = (size_t)d.M * d.H * d.SA * 64;
+    b.kv = dalloc<bf16_t>(b.kvper * 2 * NL);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (unsigned*)b.kv, b.kvper * 2 * NL / 2, 999u);
+    b.h = dalloc<bf16_t>((size_t)16 * d.D); b.h2 = dalloc<bf16_t>((size_t)16 * d.D); b.xn = dalloc<bf16_t>((size_t)16 * d.D); b.att = dalloc<bf16_t>((size_t)16 * d.D);
+    b.mid = dalloc<bf16_t>((size_t)16 * d.Fh); b.q = dalloc<bf16_t>((size_t)16 * d.D); b.nw = dalloc<bf16_t>(d.D);
+    for (bf16_t* p : {b.h, b.xn, b.att, b.q}) hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, (unsigned*)p, (size_t)16 * d.D / 2, 7u);
+    hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, (unsigned*)b.mid, (size_t)16 * d.Fh / 2, 8u);
+    hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, 0, (unsigned*)b.nw, (size_t)d.D / 2, 9u);
+    b.part = dalloc<float>((size_t)16 * d.H * 16 * 66);
+    b.rope = dalloc<float>((size_t)d.SA * 64); CK(hipMemset(b.rope, 0, (size_t)d.SA * 64 * 4));
+    b.dpos = dalloc<int>(1); CK(hipMemcpy(b.dpos, &d.pos, 4, hipMemcpyHostToDevice));
+    b.sink = dalloc<unsigned>(1);
+    CK(hipDeviceSynchronize());
+    hipStream_t st, side; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    hipEvent_t ef, ej, t0, t1; CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming)); CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+    const double wbytes = (double)b.per_layer * 2, kvbytes = (double)d.M * d.H * (d.pos + 1) * 256.0;
+    printf("rows %d, position %d, %d distinct layers per graph (%.0f MB of weights + %.1f MB of KV rows per layer; HBM floor %.1f us per layer at 6.3 TB/s)\n",
+           d.M, d.pos, NL, wbytes / 1e6, kvbytes / 1e6, (wbytes + kvbytes) / 6.3e6);
+    for (int variant = 0; variant < NVAR; ++variant) {
+        hipGraph_t graph = nullptr; hipGraphExec_t ex = nullptr;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int l = 0; l < NL; ++l) layer(d, b, l, NL, variant, st, side, ef, ej);
+        CK(hipStreamEndCapture(st, &graph));
+        CK(hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0));
+        size_t nn = 0; CK(hipGraphGetNodes(graph, nullptr, &nn));
+        for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ex, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(t0, st));
+        for (int i = 0; i < REPS; ++i) CK(hipGraphLaunch(ex, st));
+        CK(hipEventRecord(t1, st)); CK(hipEventSynchronize(t1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, t0, t1)); CK(hipGetLastError());
+        const double us = ms * 1000.0 / (REPS * NL);
+        printf("%-46s %6.2f us per layer  (%zu graph nodes per layer; x36 + tail = %.2f ms per step; %.2f TB/s of layer bytes)\n", VNAME[variant], us, nn / NL, us * 36 / 1000 + 0.03, (wbytes + kvbytes) / 1e6 / us);
+        fflush(stdout);
+        CK(hipGraphExecDestroy(ex)); CK(hipGraphDestroy(graph));
+    }
+    return 0;
+}
