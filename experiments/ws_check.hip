@@ -235,6 +235,24 @@ static void bench(int M) {
         }
         fflush(stdout);
     }
+    {   // is it the kernel BOUNDARIES of the linear chain that cannot pass a saturating streamer (end-of-kernel L2 write-back / start-of-kernel
+        // invalidate), or any kernel?  ONE long dec_gemm launch (a 6-layer stack of w1|w3 as a single 43008-row weight matrix, LOGITS epilogue)
+        // beside the attention: if this overlaps where the 6-kernel chain does not, the chain has to become one launch.
+        const int Nbig = 2 * Fh * NL; float* big = dalloc<float>((size_t)M * Nbig);
+        auto one = [&](hipStream_t st) {
+            GemmDP p; memset(&p, 0, sizeof(p)); p.W = dW; p.X = xn; p.M = M; p.N = Nbig; p.K = D; p.outf = big;
+            car_launch_dec_gemm_cfg(&p, EPI_LOGITS, car_pick_gemm_cfg(M, Nbig, D, EPI_LOGITS), st);
+        };
+        const float t1k = timed([&](int) { one(sA); });
+        const float t1c = timed([&](int it) {
+            CK(hipEventRecord(eA, sA)); CK(hipStreamWaitEvent(sB, eA, 0));
+            attention(it, sA); one(sB);
+            CK(hipEventRecord(eB, sB)); CK(hipStreamWaitEvent(sA, eB, 0));
+        });
+        printf("M=%d  ONE long dec_gemm launch (N=%d): alone %6.1f us | beside the attention %6.1f us (serial sum %6.1f)\n", M, Nbig, t1k, t1c, ta + t1k);
+        fflush(stdout);
+        CK(hipFree(big));
+    }
     // isolated per-shape times
     struct Shape { const char* name; int N, K, epi; size_t off; };
     const Shape shapes[] = {{"wqkv", 3 * D, D, EPI_QKV, 0}, {"wo", D, D, EPI_RESID, (size_t)3 * D * D}, {"w13", 2 * Fh, D, EPI_SWIGLU, (size_t)4 * D * D}, {"w2", D, Fh, EPI_RESID, (size_t)4 * D * D + (size_t)2 * Fh * D}};
