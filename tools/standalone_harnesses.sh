@@ -13,4 +13,5 @@ O=$R/gpurun_out; mkdir -p $O
 ( timeout 30 experiments/small_chain 2 631;  timeout 30 experiments/small_chain 2 200; timeout 30 experiments/small_chain 8 631; timeout 30 experiments/small_chain 16 631 ) > $O/small_chain.txt 2>&1
 timeout 30 experiments/gemm_mid > $O/gemm_mid.txt 2>&1
 timeout 60 experiments/t_check > $O/t_check.txt 2>&1
-tail -40 $O/small_chain.txt; cat $O/gemm_mid.txt; tail -30 $O/t_check.txt
+timeout 60 experiments/ws_check > $O/ws_check.txt 2>&1
+tail -40 $O/small_chain.txt; cat $O/gemm_mid.txt; tail -30 $O/t_check.txt; tail -14 $O/ws_check.txt
