@@ -250,6 +250,14 @@ static void bench(int M) {
             CK(hipEventRecord(eB, sB)); CK(hipStreamWaitEvent(sA, eB, 0));
         });
         printf("M=%d  ONE long dec_gemm launch (N=%d): alone %6.1f us | beside the attention %6.1f us (serial sum %6.1f)\n", M, Nbig, t1k, t1c, ta + t1k);
+        // the same with the GEMM enqueued FIRST (if a kernel's start-of-kernel cache invalidate has to wait for the streamer's traffic to drain,
+        // only a kernel that started before the attention can run beside it)
+        const float t1r = timed([&](int it) {
+            CK(hipEventRecord(eA, sA)); CK(hipStreamWaitEvent(sB, eA, 0));
+            one(sB); attention(it, sA);
+            CK(hipEventRecord(eB, sB)); CK(hipStreamWaitEvent(sA, eB, 0));
+        });
+        printf("M=%d  ONE long dec_gemm launch enqueued before the attention: %6.1f us per half-period\n", M, t1r);
         fflush(stdout);
         CK(hipFree(big));
     }
