@@ -1350,7 +1350,9 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     }
     const unsigned char* fmask = emb_mask ? (const unsigned char*)c->maskb.p : nullptr;      // no text-pad mask: nothing to test per position
     const int* fjmin = emb_mask ? jmin : nullptr;
-    // ---- decode-loop schedule knobs (fast mode).  Defaults from the MI355X sweep of tools/overlap_sweep.py (profiles/).
+    // ---- decode-loop schedule knobs (fast mode), all OFF by default: the MI355X sweeps of tools/overlap_sweep.py found none of them worth a
+    // per cent (profiles/r02_overlap_sweep_v1..v3, DESIGN.md §4 — a linear beside the bandwidth-saturating attention makes no progress whatever
+    // the schedule); they stay as A/B switches, and tests/test_parity_gpu.py pins that none of them changes a token.
     //   phase offset : with >= 2 chains, chain g+1 enters the step right after chain g's first wqkv (see enqueue_decode_step_fast)
     //   graph steps  : consecutive tokens captured per graph replay — the chains free-run across them (one fork / join and one phase
     //                  offset per `gsteps` tokens instead of per token); the remainder runs on a single-step graph
