@@ -9,10 +9,13 @@
 //             the linears then find their weights in the 256 MiB Infinity Cache instead of waiting on HBM.  The step streams 1 TB/s of
 //             its 8: the bandwidth for the run-ahead is free; profiles/r02_queue_check.txt shows small kernels on two queues overlap.
 //   unnorm    separate rmsnorm2 kernels instead of the fused prologue (8 kernels per layer; the > 4 rows form)
+//   lat       the linears of experiments/decode2_lat.hip: residual / position / RoPE-row loads hoisted from the epilogue into the prologue
+//             (bit-equality with dec_gemm is checked first on one layer from identical state)
 //
 // Weights: NL distinct layers (NL x 41.6 MB > 256 MiB for NL >= 7) so that every replay streams from HBM as the real 36-layer step does.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I controlar_amd/csrc experiments/small_chain.hip -o experiments/small_chain && experiments/small_chain [rows=2] [pos=631] [prefetch workgroups=256]
 #include "../controlar_amd/csrc/decode2.hip"
+#include "decode2_lat.hip"
 
 #include <cstdio>
 #include <cstdlib>
@@ -50,16 +53,18 @@ static int g_prefetch_grid = 256;                     // 256 workgroups x 256 la
 struct Dims { int M, D, Fh, H, SA, T, pos; };
 struct Bufs { bf16_t *W, *kv, *h, *h2, *xn, *att, *mid, *q, *nw; float *part, *rope; int *dpos; unsigned* sink; size_t per_layer, kvper; };
 
-enum { V_BASE = 0, V_NOSPLIT = 1, V_W8 = 2, V_PREFETCH = 3, V_UNNORM = 4, V_PREFETCH_NOSPLIT = 5, NVAR = 6 };
+enum { V_BASE = 0, V_NOSPLIT = 1, V_W8 = 2, V_PREFETCH = 3, V_UNNORM = 4, V_PREFETCH_NOSPLIT = 5, V_LAT = 6, V_LAT_NOSPLIT = 7, NVAR = 8 };
 static const char* VNAME[NVAR] = {"base (engine.hip today, 6 kernels/layer)", "nosplit attention (5 kernels/layer)", "8-wave linears", "prefetch next layer's weights (side branch)",
-                                  "separate rmsnorm2 kernels (8 kernels/layer)", "prefetch + nosplit attention"};
+                                  "separate rmsnorm2 kernels (8 kernels/layer)", "prefetch + nosplit attention",
+                                  "linears with hoisted epilogue loads (decode2_lat.hip)", "hoisted epilogue loads + nosplit attention"};
 
 static void layer(const Dims& d, const Bufs& b, int l, int NL, int variant, hipStream_t st, hipStream_t side, hipEvent_t ef, hipEvent_t ej) {
     const int D = d.D, Fh = d.Fh, M = d.M;
     bf16_t* w = b.W + b.per_layer * (l % NL);
     bf16_t *wqkv = w, *wo = w + (size_t)3 * D * D, *w13 = wo + (size_t)D * D, *w2 = w13 + (size_t)2 * Fh * D;
     bf16_t* kc = b.kv + b.kvper * 2 * (l % NL); bf16_t* vc = kc + b.kvper;
-    const bool pre = variant == V_PREFETCH || variant == V_PREFETCH_NOSPLIT, nosplit = variant == V_NOSPLIT || variant == V_PREFETCH_NOSPLIT;
+    const bool pre = variant == V_PREFETCH || variant == V_PREFETCH_NOSPLIT, nosplit = variant == V_NOSPLIT || variant == V_PREFETCH_NOSPLIT || variant == V_LAT_NOSPLIT;
+    const bool lat = variant == V_LAT || variant == V_LAT_NOSPLIT;
     const bool fuse = variant != V_UNNORM;
     if (pre) {       // fork: run ahead on the NEXT layer's weights while this layer's six kernels wait on each other
         CK(hipEventRecord(ef, st)); CK(hipStreamWaitEvent(side, ef, 0));
@@ -72,7 +77,7 @@ static void layer(const Dims& d, const Bufs& b, int l, int NL, int variant, hipS
         int cfg = car_pick_gemm_cfg(M, N, K, epi);
         if (variant == V_W8) cfg = (cfg / 10) * 10 + 1;
         const int J = (cfg / 10) % 10, Mb = (M + 15) / 16; p.w_nt = (Mb + J - 1) / J == 1;
-        if (car_launch_dec_gemm_cfg(&p, epi, cfg, st)) { printf("cfg %d rejected (N=%d K=%d)\n", cfg, N, K); exit(3); }
+        if (lat ? car_launch_dec_gemm_lat_cfg(&p, epi, cfg, st) : car_launch_dec_gemm_cfg(&p, epi, cfg, st)) { printf("cfg %d rejected (N=%d K=%d)\n", cfg, N, K); exit(3); }
     };
     GemmDP z; memset(&z, 0, sizeof(z));
     auto norm = [&](const bf16_t* hin) { Norm2P n; memset(&n, 0, sizeof(n)); n.h_in = hin; n.xn = b.xn; n.w = b.nw; n.D = D; n.eps = 1e-5f; car_launch_rmsnorm2(&n, M, st); };
@@ -124,6 +129,22 @@ int main(int argc, char** argv) {
     const double wbytes = (double)b.per_layer * 2, kvbytes = (double)d.M * d.H * (d.pos + 1) * 256.0;
     printf("rows %d, position %d, %d distinct layers per graph (%.0f MB of weights + %.1f MB of KV rows per layer; HBM floor %.1f us per layer at 6.3 TB/s)\n",
            d.M, d.pos, NL, wbytes / 1e6, kvbytes / 1e6, (wbytes + kvbytes) / 6.3e6);
+    {   // decode2_lat.hip must reproduce dec_gemm bit for bit: one layer from identical state with either kernel
+        std::vector<std::vector<unsigned short>> got[2];
+        std::vector<unsigned short> h0((size_t)16 * d.D);
+        CK(hipMemcpy(h0.data(), b.h, h0.size() * 2, hipMemcpyDeviceToHost));
+        for (int v = 0; v < 2; ++v) {
+            CK(hipMemcpy(b.h, h0.data(), h0.size() * 2, hipMemcpyHostToDevice));
+            CK(hipMemset(b.mid, 0, (size_t)16 * d.Fh * 2)); CK(hipMemset(b.q, 0, (size_t)16 * d.D * 2));
+            layer(d, b, 0, NL, v == 0 ? V_BASE : V_LAT, st, side, ef, ej);
+            CK(hipStreamSynchronize(st));
+            for (auto pr : {std::make_pair(b.h, (size_t)d.M * d.D), std::make_pair(b.mid, (size_t)16 * d.Fh), std::make_pair(b.q, (size_t)d.M * d.D), std::make_pair(b.kv, b.kvper * 2)}) {
+                std::vector<unsigned short> hbuf(pr.second); CK(hipMemcpy(hbuf.data(), pr.first, pr.second * 2, hipMemcpyDeviceToHost)); got[v].push_back(std::move(hbuf)); }
+        }
+        bool same = true; for (size_t i = 0; i < got[0].size(); ++i) same = same && got[0][i] == got[1][i];
+        printf("decode2_lat vs dec_gemm after one layer (h, mid, q, K/V cache of layer 0): %s\n", same ? "bit-identical" : "DIFFERENT");
+        CK(hipMemcpy(b.h, h0.data(), h0.size() * 2, hipMemcpyHostToDevice));
+    }
     for (int variant = 0; variant < NVAR; ++variant) {
         hipGraph_t graph = nullptr; hipGraphExec_t ex = nullptr;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
