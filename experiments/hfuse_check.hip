@@ -146,6 +146,21 @@ int main(int argc, char** argv) {
         float ms = 0; CK(hipEventElapsedTime(&ms, t0, t1));
         return ms * 1000.f / HP;
     };
+    {   // fusion must not change a bit: the six ops + the attention as separate launches vs the six fused launches, from identical state
+        std::vector<std::vector<unsigned short>> got[2];
+        for (int v = 0; v < 2; ++v) {
+            CK(hipMemset(hbuf, 0, (size_t)M * D * 2)); fill(xn, M16 * D / 2, 7u); fill(mid, M16 * Fh / 2, 9u); CK(hipMemset(oa, 0, M16 * D * 2)); CK(hipMemset(qb, 0, (size_t)M * D * 2));
+            CK(hipDeviceSynchronize());
+            int i0 = 0;
+            if (v == 0) { launch(make(0, 1, false, 0, items), 1); for (int k = 0; k < 6; ++k) launch(make(0, k, true, 0, 0), k); }
+            else for (int k = 0; k < 6; ++k) { const int n = k == 5 ? items - i0 : (int)(items * ops[k].share); launch(make(0, k, true, i0, n), k); i0 += n; }
+            CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+            for (auto pr : {std::make_pair(hbuf, (size_t)M * D), std::make_pair(mid, M16 * Fh), std::make_pair(qb, (size_t)M * D), std::make_pair(oa, M16 * D), std::make_pair(xn, M16 * D)}) {
+                std::vector<unsigned short> hb(pr.second); CK(hipMemcpy(hb.data(), pr.first, pr.second * 2, hipMemcpyDeviceToHost)); got[v].push_back(std::move(hb)); }
+        }
+        bool same = true; for (size_t i = 0; i < got[0].size(); ++i) same = same && got[0][i] == got[1][i];
+        printf("fused launches vs separate launches of the same bodies (h, mid, q, attention out, xn): %s\n", same ? "bit-identical" : "DIFFERENT");
+    }
     const float ta = timed([&](int it) { launch(make(it, 1, false, 0, items), 1); });                       // one launch of all items
     const float ta6 = timed([&](int it) { int i0 = 0; for (int k = 0; k < 6; ++k) { const int n = k == 5 ? items - i0 : (int)(items * ops[k].share); launch(make(it, k, false, i0, n), k); i0 += n; } });
     const float tl = timed([&](int it) { for (int k = 0; k < 6; ++k) launch(make(it, k, true, 0, 0), k); });
