@@ -9,7 +9,7 @@ is untouched: only the launch schedule changes).
 CAR_ATTN_PERSIST=R turns the attention into a resident grid of R workgroups per CU that walk the (sequence, head) items: a grid of
 thousands of attention workgroups keeps the dispatcher busy and the other chain's linears only get slots in its tail.
 
-usage: overlap_sweep.py [B=768] [n_new=1024] [all|quick|persist]
+usage: overlap_sweep.py [B=768] [n_new=1024] [all|quick|persist|diag|hfuse]
 """
 import json
 import os
@@ -25,7 +25,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 n_new = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 which = sys.argv[3] if len(sys.argv) > 3 else "all"
 quick = which == "quick"
-KNOBS = ["CAR_NO_GRAPH", "CAR_ATTN_PERSIST", "CAR_CHAINS", "CAR_SINGLE_CHAIN", "CAR_PHASE_OFFSET", "CAR_GRAPH_STEPS", "CAR_LINEAR_PRIO", "CAR_ATTN_VARIANT", "CAR_ATTN_NSPLIT", "CAR_ATTN_LDS_PAD"]
+KNOBS = ["CAR_HFUSE", "CAR_NO_GRAPH", "CAR_ATTN_PERSIST", "CAR_CHAINS", "CAR_SINGLE_CHAIN", "CAR_PHASE_OFFSET", "CAR_GRAPH_STEPS", "CAR_LINEAR_PRIO", "CAR_ATTN_VARIANT", "CAR_ATTN_NSPLIT", "CAR_ATTN_LDS_PAD"]
 
 cfg = C.xl_t2i(1024)
 t0 = time.time()
@@ -39,7 +39,13 @@ _inputs = {}
 
 def inputs(Bn):       # synthesised once per batch size (22 ms of host time per image)
     if Bn not in _inputs:
-        if which == "diag":       # any {-1,+1} map will do for a timing diagnosis
+        if which == "hfuse":
+    # horizontal fusion (experiments/hfuse_prep.patch / branch hfuse-prep applied): every attention launch carries a linear of the other chain.
+    # 4-wave tiles for every linear: tokens are compared with the lockstep schedule by agreement, not bit for bit.
+    big = [("lockstep (round-2 default)", {}),
+           ("hfuse", {"CAR_HFUSE": "1"}),
+           ("hfuse+graph8", {"CAR_HFUSE": "1", "CAR_GRAPH_STEPS": "8"})]
+if which == "diag":       # any {-1,+1} map will do for a timing diagnosis
             img = (torch.rand(Bn, 1, 512, 512, generator=torch.Generator().manual_seed(5)) > 0.92).to(torch.bfloat16).mul(2).sub(1).expand(Bn, 3, 512, 512).contiguous().cuda()
         else:
             img = synth.canny_like_control(Bn, 512, 512).to(torch.bfloat16).cuda()
