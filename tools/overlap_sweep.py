@@ -39,13 +39,7 @@ _inputs = {}
 
 def inputs(Bn):       # synthesised once per batch size (22 ms of host time per image)
     if Bn not in _inputs:
-        if which == "hfuse":
-    # horizontal fusion (experiments/hfuse_prep.patch / branch hfuse-prep applied): every attention launch carries a linear of the other chain.
-    # 4-wave tiles for every linear: tokens are compared with the lockstep schedule by agreement, not bit for bit.
-    big = [("lockstep (round-2 default)", {}),
-           ("hfuse", {"CAR_HFUSE": "1"}),
-           ("hfuse+graph8", {"CAR_HFUSE": "1", "CAR_GRAPH_STEPS": "8"})]
-if which == "diag":       # any {-1,+1} map will do for a timing diagnosis
+        if which == "diag":       # any {-1,+1} map will do for a timing diagnosis
             img = (torch.rand(Bn, 1, 512, 512, generator=torch.Generator().manual_seed(5)) > 0.92).to(torch.bfloat16).mul(2).sub(1).expand(Bn, 3, 512, 512).contiguous().cuda()
         else:
             img = synth.canny_like_control(Bn, 512, 512).to(torch.bfloat16).cuda()
@@ -106,6 +100,12 @@ if which == "persist":
            ("persist3+phase", dict(P, CAR_ATTN_PERSIST="3")),
            ("persist6+phase", dict(P, CAR_ATTN_PERSIST="6")),
            ("persist4 lockstep", {"CAR_ATTN_PERSIST": "4"})]
+if which == "hfuse":
+    # horizontal fusion (experiments/hfuse_prep.patch / branch hfuse-prep applied): every attention launch carries a linear of the other chain.
+    # 4-wave tiles for every linear: tokens are compared with the lockstep schedule by agreement, not bit for bit.
+    big = [("lockstep (round-2 default)", {}),
+           ("hfuse", {"CAR_HFUSE": "1"}),
+           ("hfuse+graph8", {"CAR_HFUSE": "1", "CAR_GRAPH_STEPS": "8"})]
 if which == "diag":
     # do the graph's parallel branches overlap at all?  one chain of all rows, and the two chains launched eagerly on ONE stream (strictly serial)
     big = [("2 chains, graph branches (round-2 default)", {}),
