@@ -131,6 +131,8 @@ __global__ void fill_kernel(unsigned* p, size_t n, unsigned seed) {
         p[i] = a | (b2 << 16); }
 }
 
+__global__ void ts_kernel(long long* out, int slot) { if (threadIdx.x == 0) out[slot] = wall_clock64(); }      // 100 MHz wall clock
+
 // ---- one chain-layer of linears on `st`: wo -> ffn_norm -> w1|w3 -> w2 -> attention_norm -> wqkv (what the OTHER chain runs under an attention)
 struct Layer {
     int M, D, Fh, H, SA; bf16_t *wqkv, *wo, *w13, *w2, *xn, *att, *mid, *h, *q, *kc, *vc, *nw; float* rope; int* pos;
@@ -260,6 +262,26 @@ static void bench(int M) {
         printf("M=%d  ONE long dec_gemm launch enqueued before the attention: %6.1f us per half-period\n", M, t1r);
         fflush(stdout);
         CK(hipFree(big));
+    }
+    {   // WHEN does a kernel launched on a second stream start while the attention runs?  Timestamp kernels (one lane, no memory traffic to
+        // speak of): stream A = ts0, attention, ts1; stream B (released by an event behind ts0) = ts2 .. ts7 as a chain of six dependent launches.
+        // If ts2 - ts0 is a few us, trivial kernels start freely beside the attention and only memory-heavy ones stall (explanation (b) of
+        // DESIGN.md §4); if ts2 lands at ts1, NO kernel starts until the attention's traffic has drained (explanation (a)).
+        long long* dts = dalloc<long long>(16); CK(hipMemset(dts, 0, 16 * 8));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipDeviceSynchronize());
+            hipLaunchKernelGGL(ts_kernel, dim3(1), dim3(64), 0, sA, dts, 0);
+            CK(hipEventRecord(eA, sA)); CK(hipStreamWaitEvent(sB, eA, 0));
+            attention(rep, sA);
+            hipLaunchKernelGGL(ts_kernel, dim3(1), dim3(64), 0, sA, dts, 1);
+            for (int k = 2; k < 8; ++k) hipLaunchKernelGGL(ts_kernel, dim3(1), dim3(64), 0, sB, dts, k);
+            CK(hipDeviceSynchronize());
+            long long h[8]; CK(hipMemcpy(h, dts, sizeof(h), hipMemcpyDeviceToHost));
+            printf("M=%d  timestamps (us after ts0): attention done %.1f | first kernel on the other stream ran at %.1f, the sixth of its chain at %.1f\n", M,
+                   (h[1] - h[0]) / 100.0, (h[2] - h[0]) / 100.0, (h[7] - h[0]) / 100.0);
+        }
+        fflush(stdout);
+        CK(hipFree(dts));
     }
     // isolated per-shape times
     struct Shape { const char* name; int N, K, epi; size_t off; };
