@@ -280,6 +280,21 @@ static void bench(int M) {
             printf("M=%d  timestamps (us after ts0): attention done %.1f | first kernel on the other stream ran at %.1f, the sixth of its chain at %.1f\n", M,
                    (h[1] - h[0]) / 100.0, (h[2] - h[0]) / 100.0, (h[7] - h[0]) / 100.0);
         }
+        // the same with six rmsnorm2 launches (384 rows x 2.5 KB read + written each: light but real memory traffic) between two timestamps
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipDeviceSynchronize());
+            hipLaunchKernelGGL(ts_kernel, dim3(1), dim3(64), 0, sA, dts, 0);
+            CK(hipEventRecord(eA, sA)); CK(hipStreamWaitEvent(sB, eA, 0));
+            attention(rep, sA);
+            hipLaunchKernelGGL(ts_kernel, dim3(1), dim3(64), 0, sA, dts, 1);
+            hipLaunchKernelGGL(ts_kernel, dim3(1), dim3(64), 0, sB, dts, 2);
+            for (int k = 0; k < 6; ++k) { Norm2P n; memset(&n, 0, sizeof(n)); n.h_in = hbuf; n.xn = xn; n.w = nw; n.D = D; n.eps = 1e-5f; car_launch_rmsnorm2(&n, M, sB); }
+            hipLaunchKernelGGL(ts_kernel, dim3(1), dim3(64), 0, sB, dts, 3);
+            CK(hipDeviceSynchronize());
+            long long h[4]; CK(hipMemcpy(h, dts, sizeof(h), hipMemcpyDeviceToHost));
+            printf("M=%d  timestamps (us after ts0): attention done %.1f | six rmsnorm2 launches on the other stream ran from %.1f to %.1f\n", M,
+                   (h[1] - h[0]) / 100.0, (h[2] - h[0]) / 100.0, (h[3] - h[0]) / 100.0);
+        }
         fflush(stdout);
         CK(hipFree(dts));
     }
