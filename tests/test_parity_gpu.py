@@ -141,8 +141,9 @@ def test_error_paths_raise():
 
 
 def test_two_chain_decode_large_batch():
-    """B=48 (cfg=1) takes the two-chain path (two forked graph branches of 24 sequences); teacher-forced on the
-    oracle's fp32 tokens the logits must stay within the fast-mode tolerance, and rows must not leak across chains."""
+    """B=48 (cfg=1): 48 rows = 3 m-blocks in one chain (chains are only cut from 192 sequences up; the multi-chain schedules at this size
+    are covered by test_chain_schedule_knobs_do_not_change_tokens, at the bench size by tests/test_bench_shapes_gpu.py); teacher-forced on the
+    oracle's fp32 tokens the logits must stay within the fast-mode tolerance, and identical sequences in different m-blocks must agree."""
     from controlar_amd import config as C, synth
     from controlar_amd.engine import Engine
     from oracle import controlar_oracle as O
@@ -322,8 +323,9 @@ def test_stochastic_sampler_matches_reference_distribution(temperature, top_k, t
 
 @pytest.mark.parametrize("single_chain", [False, True])
 def test_cfg_large_batch_chains_and_row_tiling(single_chain, monkeypatch):
-    """CFG with 2B = 144 rows: by default the images are cut into 3 groups whose rows are laid out [cond | uncond] per group and
-    decoded as 3 concurrent chains; with CAR_SINGLE_CHAIN the one 144-row chain exercises the 64-row tiling of dec_linear."""
+    """CFG with 2B = 144 rows laid out [cond | uncond]: nine m-blocks (ragged J = 4 tiles) in one chain — below the 192-sequence
+    threshold both parametrisations take the single-chain path today; CAR_SINGLE_CHAIN is kept so that the pair stays meaningful if the
+    threshold moves."""
     if single_chain:
         monkeypatch.setenv("CAR_SINGLE_CHAIN", "1")
     from controlar_amd import config as C, synth
