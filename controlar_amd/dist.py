@@ -21,7 +21,10 @@ def pad_to_world(G: int, world: int) -> int:
 
 def packed_layout(G: int, H: int, W: int, T: int, cap: int):
     """Byte sizes (img bf16 [G,3,H,W], emb bf16 [G,T,cap], mask int64 [G,T]) of the packed input buffer; every section starts 8-byte aligned."""
-    return G * 3 * H * W * 2, G * T * cap * 2, G * T * 8
+    n_img, n_emb, n_mask = G * 3 * H * W * 2, G * T * cap * 2, G * T * 8
+    if n_img % 8 or n_emb % 8:
+        raise ValueError(f"packed input sections must be 8-byte aligned (G={G}, H={H}, W={W}, T={T}, cap={cap}): pad the batch or the caption width")
+    return n_img, n_emb, n_mask
 
 
 def packed_views(buf: torch.Tensor, G: int, H: int, W: int, T: int, cap: int):
