@@ -156,6 +156,13 @@ def b_c2i(block_size: int = 256) -> PathConfig:
                                     condition_type="canny"), vit=vit_small16(), vq=VQConfig())
 
 
+def l_c2i(block_size: int = 256) -> PathConfig:
+    """LlamaGen-L class-conditional (reference gpt.py:545 GPT_L: 24 layers, 16 heads, dim 1024) + ViT-S/16 control — the size of the released
+    ControlAR c2i depth / canny checkpoints next to GPT-B."""
+    return PathConfig(gpt=GPTConfig(dim=1024, n_layer=24, n_head=16, block_size=block_size, cls_token_num=1, model_type="c2i",
+                                    condition_type="depth"), vit=vit_small16(), vq=VQConfig())
+
+
 def tiny_c2i(block_size: int = 64, vocab_size: int = 1024, num_classes: int = 10) -> PathConfig:
     return PathConfig(
         gpt=GPTConfig(dim=256, n_layer=6, n_head=4, vocab_size=vocab_size, block_size=block_size, cls_token_num=1,

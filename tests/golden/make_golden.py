@@ -326,7 +326,17 @@ def case_c2i_b():
     run_c2i("b_c2i_canny_fixtures_cfg1", C.b_c2i(256), imgs, labels, 1.0)
 
 
+def case_c2i_l_depth():
+    """GPT-L c2i on the reference's depth fixtures: condition/example/c2i/depth/{101,4351,10601,48901}.png + .npy labels (sample_c2i.py:92-99)."""
+    from PIL import Image
+    ids = [101, 4351, 10601, 48901]
+    imgs = np.stack([np.array(Image.open(os.path.join(REF, f"condition/example/c2i/depth/{i}.png"))) for i in ids]).astype(np.uint8)
+    labels = np.array([int(np.load(os.path.join(REF, f"condition/example/c2i/depth/{i}.npy"))[0]) for i in ids], dtype=np.int64)
+    run_c2i("l_c2i_depth_fixtures_cfg1", C.l_c2i(256), imgs, labels, 1.0)
+
+
 CASES["tiny_c2i_cfg1"] = case_c2i_tiny
+CASES["l_c2i_depth_fixtures_cfg1"] = case_c2i_l_depth
 CASES["b_c2i_canny_fixtures_cfg1"] = case_c2i_b
 
 

@@ -96,7 +96,8 @@ def test_resize_restatements_match_torch():
         assert torch.equal(O.nearest_src_index(o, i), ref.view(-1).long())
 
 
-@pytest.mark.parametrize("name,mk", [("tiny_c2i_cfg1", lambda: C.tiny_c2i(64)), ("b_c2i_canny_fixtures_cfg1", lambda: C.b_c2i(256))])
+@pytest.mark.parametrize("name,mk", [("tiny_c2i_cfg1", lambda: C.tiny_c2i(64)), ("b_c2i_canny_fixtures_cfg1", lambda: C.b_c2i(256)),
+                                     ("l_c2i_depth_fixtures_cfg1", lambda: C.l_c2i(256))])
 def test_oracle_c2i_tracks_reference_bf16(name, mk, golden_dir):
     """c2i (BASELINE config 1): the reference only runs in bf16 (gpt.py:427), so its golden pins the oracle
     teacher-forced within bf16 round-off — for the oracle's bf16 mode and for its fp32 mode (the GPU ground truth)."""
@@ -111,11 +112,14 @@ def test_oracle_c2i_tracks_reference_bf16(name, mk, golden_dir):
     st = int(gold["logits_step_stride"]); vs = 2 if st == 1 else 4
     ref = gold["logits"].astype(np.float32)
     n_new = forced.shape[1]
-    dtypes = [torch.float32] if name.startswith("b_") else [torch.bfloat16, torch.float32]
+    dtypes = [torch.float32] if name.startswith(("b_", "l_")) else [torch.bfloat16, torch.float32]
     for dtype in dtypes:
         toks, logits = O.generate(gsd, cfg, labels, n_new, None, cfg_scale=1.0, condition=x, dtype=dtype, forced_tokens=forced, return_logits=True)
         d = np.abs(logits.numpy()[:, ::st, ::vs] - ref)
-        assert d.max() < 0.8 and d.mean() < 0.08, (dtype, d.max(), d.mean())
+        # the reference's bf16 drift against fp32 arithmetic grows with depth: 0.8 / 0.08 at 12 layers (GPT-B), measured 0.94 / 0.155 at 24 (GPT-L),
+        # 1.45 / 0.24 at 36 (GPT-XL, tests/golden/xl_canny_512_cfg1_refbf16.npz: the reference against ITSELF in fp32)
+        k = max(1.0, cfg.gpt.n_layer / 12.0)
+        assert d.max() < 0.8 * k and d.mean() < 0.08 * k, (dtype, d.max(), d.mean())
         agree = toks.numpy() == gold["tokens"]
         assert agree[gold["margin"] > 0.5].all() and agree.mean() > 0.9, (dtype, agree.mean())
 
