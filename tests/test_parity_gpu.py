@@ -254,6 +254,8 @@ def test_gpt_xl_512_full_size_exact_and_fast():
     eng.close()
 
 
+# (tests/golden/l_c2i_depth_fixtures_cfg1.npz — GPT-L on the reference's depth fixtures — is pinned on the CPU side by tests/test_oracle_golden.py;
+#  it joins this list, with the depth-scaled tolerance used there, once a GPU run of it has been seen)
 @pytest.mark.parametrize("name,mk", [("tiny_c2i_cfg1", "tiny"), ("b_c2i_canny_fixtures_cfg1", "b")])
 def test_c2i_class_conditional(name, mk):
     """BASELINE config 1 (LlamaGen c2i + ViT-S/16 control, gpt.py): exact mode vs the fp32 oracle bit-for-bit on tokens;
