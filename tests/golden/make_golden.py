@@ -70,7 +70,8 @@ def build_ref_gpt(cfg: C.PathConfig, sd, dtype):
 def build_ref_vq(cfg: C.VQConfig, sd):
     m = ref_vq.VQModel(ref_vq.ModelArgs(codebook_size=cfg.codebook_size,
                                         codebook_embed_dim=cfg.codebook_embed_dim,
-                                        decoder_ch_mult=list(cfg.ch_mult), z_channels=cfg.z_channels))
+                                        encoder_ch_mult=list(cfg.ch_mult), decoder_ch_mult=list(cfg.ch_mult),      # VQ_16 / VQ_8 set both (vq_model.py:415-420)
+                                        z_channels=cfg.z_channels))
     if cfg.ch != 128:
         # tiny test architecture: the reference's ModelArgs has no `ch` knob, so both halves are rebuilt at the test width
         # (synth.vq_state_dict emits encoder.* / quant_conv.* since car_vq_encode exists; strict=False only forgives the buffers)
@@ -162,6 +163,19 @@ def case_vq16_real(name="vq16_real_8x8"):
     print(name, px.shape, float(px.abs().max()), float(px.abs().mean()))
 
 
+def case_vq8_real(name="vq8_real_8x8"):
+    """The VQ-8 variant (vq_model.py:415-417: ch_mult (1, 2, 2, 4), three upsampling levels) at its real width on an 8x8 token grid -> 64x64 pixels."""
+    cfg = C.VQConfig(ch_mult=(1, 2, 2, 4))
+    sd = synth.vq_state_dict(cfg, seed=3)
+    m = build_ref_vq(cfg, sd)
+    g = torch.Generator().manual_seed(8)
+    toks = torch.randint(0, cfg.codebook_size, (2, 64), generator=g, dtype=torch.int32)
+    with torch.no_grad():
+        px = m.decode_code(toks, [2, 8, 8, 8])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), tokens=toks.numpy(), pixels=px.numpy())
+    print(name, px.shape, float(px.abs().max()), float(px.abs().mean()))
+
+
 def case_vq16_real_512(name="vq16_real_32x32"):
     """The real VQ-16 decoder at the bench's size: 32x32 tokens -> 512x512 pixels (vq_model.py:53-56,174-195).  The fixture
     keeps a strided pixel lattice plus two dense patches (image corner and centre) so that tiling/chunking errors show."""
@@ -201,6 +215,7 @@ CASES = {
     "tiny_mask_edges": lambda: run_case("tiny_mask_edges", C.tiny_t2i(64, "canny"), 3, 128, 128, 1.5, vq=False, lengths=[1, 120, 40]),
     "tiny_no_mask": lambda: run_case("tiny_no_mask", C.tiny_t2i(64, "canny"), 2, 128, 128, 1.0, vq=False, no_mask=True),
     "vq16_real_8x8": case_vq16_real,
+    "vq8_real_8x8": case_vq8_real,
     "vq16_real_32x32": case_vq16_real_512,
     # GPT-B sized, 256 tokens
     "b_canny_256_cfg4": lambda: run_case("b_canny_256_cfg4", C.b_t2i(256, "small", "canny"), 1, 256, 256, 4.0,

@@ -71,6 +71,16 @@ def test_oracle_vq16_real_arch(golden_dir):
     np.testing.assert_allclose(px.numpy(), gold["pixels"], atol=5e-4, rtol=1e-4)
 
 
+def test_oracle_vq8_real_arch(golden_dir):
+    """The VQ-8 variant (ch_mult (1, 2, 2, 4): three upsampling levels, vq_model.py:415-417) against the reference's pixels."""
+    gold = np.load(os.path.join(golden_dir, "vq8_real_8x8.npz"))
+    cfg = C.VQConfig(ch_mult=(1, 2, 2, 4))
+    sd = synth.vq_state_dict(cfg, seed=3)
+    px = O.vq_decode_code(sd, cfg, torch.from_numpy(gold["tokens"]), [2, 8, 8, 8])
+    assert px.shape == (2, 3, 64, 64)
+    np.testing.assert_allclose(px.numpy(), gold["pixels"], atol=5e-4, rtol=1e-4)
+
+
 def test_oracle_bf16_mode_tracks_reference_bf16(golden_dir):
     """bf16 is not thread-stable even inside the reference; teacher-forced on the
     reference's own bf16 tokens the oracle's bf16 logits must sit within bf16 round-off."""
