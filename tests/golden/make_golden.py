@@ -220,6 +220,10 @@ CASES = {
     # GPT-B sized, 256 tokens
     "b_canny_256_cfg4": lambda: run_case("b_canny_256_cfg4", C.b_t2i(256, "small", "canny"), 1, 256, 256, 4.0,
                                          vq=False, keep_logits=16),
+    # the REAL DINOv2-base control encoder (768 / 12 heads / 12 layers) with the bicubic resize, CFG and control_strength, GPT-B sized (BASELINE
+    # configs 3 / 5 use this encoder under GPT-XL; the GPU test of config 3 checks the adapter against the oracle, which this case pins)
+    "b_depth_base_256_cfg1p5": lambda: run_case("b_depth_base_256_cfg1p5", C.b_t2i(256, "base", "depth"), 1, 256, 256, 1.5,
+                                                control_strength=0.6, control="smooth", vq=False, keep_logits=16),
     # BASELINE config 2 at full size (GPT-XL, 512x512, 1024 tokens), B=1; ~2-4 min of CPU
     "xl_canny_512_cfg1": lambda: run_case("xl_canny_512_cfg1", C.xl_t2i(1024, "small", "canny"), 1, 512, 512, 1.0,
                                           vq=False, keep_logits=64),

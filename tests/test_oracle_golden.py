@@ -64,19 +64,21 @@ def test_oracle_matches_reference_fp32(name, golden_dir):
 
 
 @pytest.mark.parametrize("name,mk", [("b_canny_256_cfg4", lambda: C.b_t2i(256, "small", "canny")),
+                                     ("b_depth_base_256_cfg1p5", lambda: C.b_t2i(256, "base", "depth")),
                                      ("xl_canny_512_cfg1", lambda: C.xl_t2i(1024, "small", "canny"))])
 def test_oracle_matches_reference_fp32_at_model_size(name, mk, golden_dir):
-    """GPT-B (256 tokens, cfg 4) and GPT-XL at the bench's full size (512x512 = 1024 tokens, cfg 1; ~2 minutes of CPU): greedy tokens
+    """GPT-B (256 tokens, cfg 4; and with the real DINOv2-base encoder, bicubic resize, cfg 1.5, control_strength 0.6) and GPT-XL at the bench's full size (512x512 = 1024 tokens, cfg 1; ~2 minutes of CPU): greedy tokens
     bit-identical to the unmodified reference over the whole image, logits and stage samples to fp32 round-off."""
     cfg = mk()
     gold = np.load(os.path.join(golden_dir, name + ".npz"))
-    B, H, W, seed, img, emb, mask = _inputs(cfg, gold, "canny")
+    B, H, W, seed, img, emb, mask = _inputs(cfg, gold, "smooth" if "depth" in name else "canny")      # depth: the REAL DINOv2-base, bicubic resize
     gsd, _ = synth.path_state_dicts(cfg, seed=seed)
     n_new = (H // 16) * (W // 16)
     toks, logits, st = O.generate(gsd, cfg, emb, n_new, mask, cfg_scale=float(gold["cfg_scale"]), condition=img,
                                   control_strength=float(gold["control_strength"]), return_logits=True, return_stages=True)
     assert np.array_equal(toks.numpy(), gold["tokens"]), int((toks.numpy() != gold["tokens"]).sum())
     np.testing.assert_allclose(logits.numpy()[:, gold["logits_steps"]][:, :, ::4], gold["logits"], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(st["adapter_out"].numpy()[:, ::7, ::5], gold["adapter_out"], atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(st["adapter_mlp_out"].numpy()[:, ::7, ::5], gold["adapter_mlp_out"], atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(st["ctrl"][2].numpy()[:B, ::7, ::5], gold["ctrl2"], atol=2e-4, rtol=1e-4)
 
