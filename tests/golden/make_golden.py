@@ -224,6 +224,9 @@ CASES = {
     # configs 3 / 5 use this encoder under GPT-XL; the GPU test of config 3 checks the adapter against the oracle, which this case pins)
     "b_depth_base_256_cfg1p5": lambda: run_case("b_depth_base_256_cfg1p5", C.b_t2i(256, "base", "depth"), 1, 256, 256, 1.5,
                                                 control_strength=0.6, control="smooth", vq=False, keep_logits=16),
+    # BASELINE config 4's geometry at full size (sample_t2i_MR.py:73-78: 768x512 -> 48 x 32 tokens, rope grid 48, block_size 2304, S_max 1656; the real
+    # DINOv2-small at 672x448 with interpolated position embeddings), GPT-B sized so that the CPU reference finishes in a minute
+    "b_mr_768x512_cfg4": lambda: run_case("b_mr_768x512_cfg4", C.b_t2i(2304, "small", "canny"), 1, 768, 512, 4.0, vq=False, keep_logits=64),
     # BASELINE config 2 at full size (GPT-XL, 512x512, 1024 tokens), B=1; ~2-4 min of CPU
     "xl_canny_512_cfg1": lambda: run_case("xl_canny_512_cfg1", C.xl_t2i(1024, "small", "canny"), 1, 512, 512, 1.0,
                                           vq=False, keep_logits=64),

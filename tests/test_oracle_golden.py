@@ -65,9 +65,11 @@ def test_oracle_matches_reference_fp32(name, golden_dir):
 
 @pytest.mark.parametrize("name,mk", [("b_canny_256_cfg4", lambda: C.b_t2i(256, "small", "canny")),
                                      ("b_depth_base_256_cfg1p5", lambda: C.b_t2i(256, "base", "depth")),
+                                     ("b_mr_768x512_cfg4", lambda: C.b_t2i(2304, "small", "canny")),
                                      ("xl_canny_512_cfg1", lambda: C.xl_t2i(1024, "small", "canny"))])
 def test_oracle_matches_reference_fp32_at_model_size(name, mk, golden_dir):
-    """GPT-B (256 tokens, cfg 4; and with the real DINOv2-base encoder, bicubic resize, cfg 1.5, control_strength 0.6) and GPT-XL at the bench's full size (512x512 = 1024 tokens, cfg 1; ~2 minutes of CPU): greedy tokens
+    """GPT-B (256 tokens, cfg 4; with the real DINOv2-base encoder, bicubic resize, cfg 1.5, control_strength 0.6; BASELINE config 4's multi-resolution
+    geometry 768x512 = 48 x 32 tokens on a rope grid of 48, DINOv2 at 672x448) and GPT-XL at the bench's full size (512x512 = 1024 tokens, cfg 1; ~2 minutes of CPU): greedy tokens
     bit-identical to the unmodified reference over the whole image, logits and stage samples to fp32 round-off."""
     cfg = mk()
     gold = np.load(os.path.join(golden_dir, name + ".npz"))
