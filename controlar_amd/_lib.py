@@ -61,6 +61,7 @@ SYMBOLS = {
     "car_destroy": (None, [C.c_void_p]),
     "car_last_error": (C.c_char_p, [C.c_void_p]),
     "car_abi_version": (C.c_int, []),
+    "car_build_id": (C.c_char_p, []),
     "car_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "car_finalize_weights": (C.c_int, [C.c_void_p]),
     "car_export_packed": (C.c_int, [C.c_void_p, C.c_char_p]),

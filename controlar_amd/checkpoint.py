@@ -20,16 +20,33 @@ import torch
 
 from .config import PathConfig
 
-PACK_FORMAT = "CARPK02"          # bump together with engine.hip kPackMagic
+PACK_FORMAT = "CARPK03"          # bump together with engine.hip kPackMagic
 
 
-def load_checkpoint(path: str, *, vq: bool = False) -> Dict[str, torch.Tensor]:
-    """The state dict stored in `path`, by the reference's rules (sample_t2i.py:48-49 for ``vq=True``, :64-83 otherwise)."""
+def _torch_load(path: str, trust: bool = False):
+    """``torch.load`` for the checkpoints the reference's training scripts write:
+    ``{"model", "optimizer", "steps", "args": argparse.Namespace}`` (train_t2i_canny.py:208, train_c2i_depth.py:252).
+    The weights-only unpickler stays on; ``argparse.Namespace`` (a plain attribute bag) is allow-listed for it.  Anything else the
+    unpickler refuses is an error unless the caller states that the file is trusted (``trust=True`` -> full pickle)."""
+    import argparse
+    import pickle
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError:
+        if not trust:
+            raise
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_checkpoint(path: str, *, vq: bool = False, trust_pickle: bool = False) -> Dict[str, torch.Tensor]:
+    """The state dict stored in `path`, by the reference's rules (sample_t2i.py:48-49 for ``vq=True``, :64-83 otherwise).
+    `trust_pickle`: fall back to the full unpickler for a file whose non-tensor entries the weights-only loader refuses."""
     _, ext = os.path.splitext(path)
     if ext.lower() == ".safetensors":
         from safetensors.torch import load_file
         return load_file(path)
-    checkpoint = torch.load(path, map_location="cpu", weights_only=True)
+    checkpoint = _torch_load(path, trust=trust_pickle)
     if vq:
         return checkpoint["model"]
     if "model" in checkpoint:            # ddp
@@ -132,7 +149,7 @@ def key_report(expected: Iterable[str], provided: Iterable[str], ignored: Iterab
 
 # ---------------------------------------------------------------------------------------------- packed-image cache
 def content_key(paths: Iterable[str], cfg_bytes: bytes, extra: str = "") -> str:
-    """blake2b over the checkpoint files' CONTENT + the car_config bytes + the pack format tag."""
+    """blake2b over the checkpoint files' CONTENT + the car_config bytes + the pack format tag + `extra` (precision, library build id)."""
     h = hashlib.blake2b(digest_size=16)
     h.update(PACK_FORMAT.encode()); h.update(cfg_bytes); h.update(extra.encode())
     for p in paths:
@@ -163,7 +180,9 @@ def load_engine_from_checkpoints(engine, gpt_path: Optional[str] = None, vq_path
     if use_cache:
         cdir = cache_dir or default_cache_dir()
         os.makedirs(cdir, exist_ok=True)
-        cfile = os.path.join(cdir, content_key(paths, bytes(engine._cc), engine.precision) + ".carpk")
+        # the images are a private format of one library build: its id is part of the key (and of the file header, engine.hip)
+        build = engine.lib.car_build_id().decode()
+        cfile = os.path.join(cdir, content_key(paths, bytes(engine._cc), engine.precision + "|" + build) + ".carpk")
         info["file"] = cfile
         if os.path.exists(cfile):
             rc = engine.lib.car_import_packed(engine._h, cfile.encode())

@@ -5,9 +5,12 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p _obj
+# build id = hash of every source: the packed-weight cache (car_export_packed / car_import_packed) is private to one build
+BID=$(cat *.hip *.h ../../include/controlar_hip.h | sha1sum | cut -c1-40)
+if [ ! -f _obj/build_id.h ] || ! grep -q "$BID" _obj/build_id.h; then echo "#define CAR_BUILD_ID \"$BID\"" > _obj/build_id.h; fi
 pids=()
 for f in gemm ops decode decode2 pack canny t5 attn engine; do
-  if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ car_common.h -nt _obj/$f.o ] || [ ../../include/controlar_hip.h -nt _obj/$f.o ]; then
+  if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ car_common.h -nt _obj/$f.o ] || { [ $f = engine ] && [ _obj/build_id.h -nt _obj/$f.o ]; } || [ ../../include/controlar_hip.h -nt _obj/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o _obj/$f.o &
     pids+=($!)
   fi

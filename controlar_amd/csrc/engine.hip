@@ -177,6 +177,10 @@ static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------- lifecycle
 extern "C" int car_abi_version(void) { return CAR_ABI_VERSION; }
+// hash of every source of this library (build.sh -> _obj/build_id.h): the packed-weight images are a private format of ONE build,
+// so the cache file header and the cache key (controlar_amd/checkpoint.py content_key) both carry it
+#include "_obj/build_id.h"
+extern "C" const char* car_build_id(void) { return CAR_BUILD_ID; }
 
 extern "C" const char* car_last_error(const car_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -661,9 +665,9 @@ extern "C" int car_finalize_weights(car_ctx* c) {
 // The reference re-reads and re-loads its checkpoints on every start (sample_t2i.py:64-83; demo/model.py:66-75 even per request).
 // car_export_packed writes every device-resident weight image of a finalised context (row-major operands, MFMA-fragment / e4m3
 // images, scales, conv layouts) plus the host-side tables into one file; car_import_packed restores them with plain copies —
-// no conversion, no packing — into a context created with the SAME car_config.  Layout: magic, car_config, entry count, then
+// no conversion, no packing — into a context created with the SAME car_config by the SAME build.  Layout: magic, build id, car_config, entry count, then
 // per entry {kind, name, shape, numel, bytes, payload}.  The caller keys the file (controlar_amd/checkpoint.py: content hash).
-static const char kPackMagic[8] = {'C', 'A', 'R', 'P', 'K', '0', '2', 0};
+static const char kPackMagic[8] = {'C', 'A', 'R', 'P', 'K', '0', '3', 0};
 static bool same_config(const car_config& a, const car_config& b) {
     car_config x = a, y = b; x.stream_priority = y.stream_priority = 0;
     return memcmp(&x, &y, sizeof(car_config)) == 0;
@@ -674,7 +678,8 @@ extern "C" int car_export_packed(car_ctx* c, const char* path) {
     (void)hipDeviceSynchronize();
     FILE* f = fopen(path, "wb");
     if (!f) FAIL(c, "car_export_packed: cannot open %s for writing", path);
-    bool ok = fwrite(kPackMagic, 1, 8, f) == 8 && fwrite(&c->cfg, sizeof(car_config), 1, f) == 1;
+    char bid[48]; memset(bid, 0, sizeof(bid)); strncpy(bid, CAR_BUILD_ID, sizeof(bid) - 1);
+    bool ok = fwrite(kPackMagic, 1, 8, f) == 8 && fwrite(bid, 1, sizeof(bid), f) == sizeof(bid) && fwrite(&c->cfg, sizeof(car_config), 1, f) == 1;
     const uint64_t n = c->w.size() + c->host_keep.size();
     ok = ok && fwrite(&n, 8, 1, f) == 1;
     std::vector<unsigned char> buf;
@@ -696,32 +701,52 @@ extern "C" int car_export_packed(car_ctx* c, const char* path) {
     if (!ok) { remove(path); FAIL(c, "car_export_packed: short write to %s", path); }
     return 0;
 }
-extern "C" int car_import_packed(car_ctx* c, const char* path) {
-    if (!c || !path) return -1;
+static int import_packed_impl(car_ctx* c, const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) FAIL(c, "car_import_packed: cannot open %s", path);
-    char magic[8]; car_config cfg; uint64_t n = 0;
-    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kPackMagic, 8) || fread(&cfg, sizeof(car_config), 1, f) != 1 || fread(&n, 8, 1, f) != 1) { fclose(f); FAIL(c, "car_import_packed: %s is not a packed-weight file of this library version", path); }
-    if (!same_config(cfg, c->cfg)) { fclose(f); FAIL(c, "car_import_packed: %s was written for a different car_config", path); }
-    std::vector<unsigned char> buf;
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+    (void)fseek(f, 0, SEEK_END); const long fsize = ftell(f); (void)fseek(f, 0, SEEK_SET);
+    char magic[8], bid[48]; car_config cfg; uint64_t n = 0;
+    if (fsize < 0 || fread(magic, 1, 8, f) != 8 || memcmp(magic, kPackMagic, 8) || fread(bid, 1, sizeof(bid), f) != sizeof(bid) || fread(&cfg, sizeof(car_config), 1, f) != 1 || fread(&n, 8, 1, f) != 1)
+        FAIL(c, "car_import_packed: %s is not a packed-weight file of this library version", path);
+    { char mine[48]; memset(mine, 0, sizeof(mine)); strncpy(mine, CAR_BUILD_ID, sizeof(mine) - 1);
+      if (memcmp(bid, mine, sizeof(mine))) FAIL(c, "car_import_packed: %s was written by a different build of the library (packed layouts are per build)", path); }
+    if (!same_config(cfg, c->cfg)) FAIL(c, "car_import_packed: %s was written for a different car_config", path);
+    if (n > (1u << 20)) FAIL(c, "car_import_packed: %s is corrupt (entry count)", path);
+    // two passes: everything is read and validated on the host first, so a corrupt file leaves the context untouched
+    struct Ent { uint32_t kind; std::string name; std::vector<int64_t> shape; int64_t numel; std::vector<unsigned char> data; };
+    std::vector<Ent> ents; ents.reserve((size_t)n);
     for (uint64_t i = 0; i < n; ++i) {
-        uint32_t kind = 0, nl = 0, nd = 0; int64_t numel = 0; uint64_t bytes = 0;
-        bool ok = fread(&kind, 4, 1, f) == 1 && fread(&nl, 4, 1, f) == 1 && nl < 4096;
-        std::string name((size_t)nl, ' ');
-        ok = ok && fread(&name[0], 1, nl, f) == nl && fread(&nd, 4, 1, f) == 1 && nd <= 8;
-        std::vector<int64_t> shape(nd);
-        if (ok && nd) ok = fread(shape.data(), 8, nd, f) == nd;
-        ok = ok && fread(&numel, 8, 1, f) == 1 && fread(&bytes, 8, 1, f) == 1;
-        if (ok) { buf.resize(bytes); if (bytes) ok = fread(buf.data(), 1, bytes, f) == bytes; }
-        if (!ok) { fclose(f); FAIL(c, "car_import_packed: %s is truncated", path); }
-        if (kind == 1) { std::vector<float> v((size_t)numel); memcpy(v.data(), buf.data(), bytes); c->host_keep[name] = std::move(v); continue; }
-        if (ensure_w(c, name, bytes, shape, numel)) { fclose(f); return -1; }
-        if (bytes && hipMemcpy(c->w[name].p, buf.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { fclose(f); FAIL(c, "car_import_packed: upload of %s failed", name.c_str()); }
-        if (ends_with(name, "feed_forward.w13.weight")) c->w13_seen[name] = 3;
+        Ent e; uint32_t nl = 0, nd = 0; uint64_t bytes = 0;
+        bool ok = fread(&e.kind, 4, 1, f) == 1 && fread(&nl, 4, 1, f) == 1 && nl > 0 && nl < 4096 && e.kind <= 1;
+        if (ok) { e.name.assign((size_t)nl, ' '); ok = fread(&e.name[0], 1, nl, f) == nl && fread(&nd, 4, 1, f) == 1 && nd <= 8; }
+        if (ok && nd) { e.shape.resize(nd); ok = fread(e.shape.data(), 8, nd, f) == nd; }
+        ok = ok && fread(&e.numel, 8, 1, f) == 1 && fread(&bytes, 8, 1, f) == 1;
+        const long here = ok ? ftell(f) : -1;
+        ok = ok && here >= 0 && e.numel >= 0 && bytes <= (uint64_t)(fsize - here);             // the payload must fit in what is left of the file
+        if (ok && e.kind == 1) ok = bytes == (uint64_t)e.numel * 4;                              // host tables are fp32
+        if (ok && e.kind == 0) {                                                                 // device images: 1, 2 or 4 bytes per element of the stated shape
+            int64_t prod = 1; for (int64_t d : e.shape) { if (d < 0 || (d && prod > INT64_MAX / d)) { ok = false; break; } prod *= d; }
+            ok = ok && prod == e.numel && (bytes == (uint64_t)e.numel || bytes == (uint64_t)e.numel * 2 || bytes == (uint64_t)e.numel * 4);
+        }
+        if (ok) { e.data.resize((size_t)bytes); if (bytes) ok = fread(e.data.data(), 1, (size_t)bytes, f) == bytes; }
+        if (!ok) FAIL(c, "car_import_packed: %s is truncated or corrupt (entry %llu)", path, (unsigned long long)i);
+        ents.push_back(std::move(e));
     }
-    fclose(f);
+    for (Ent& e : ents) {
+        if (e.kind == 1) { std::vector<float> v((size_t)e.numel); if (e.numel) memcpy(v.data(), e.data.data(), e.data.size()); c->host_keep[e.name] = std::move(v); continue; }
+        if (ensure_w(c, e.name, e.data.size(), e.shape, e.numel)) return -1;
+        if (!e.data.empty() && hipMemcpy(c->w[e.name].p, e.data.data(), e.data.size(), hipMemcpyHostToDevice) != hipSuccess) FAIL(c, "car_import_packed: upload of %s failed", e.name.c_str());
+        if (ends_with(e.name, "feed_forward.w13.weight")) c->w13_seen[e.name] = 3;
+        e.data = std::vector<unsigned char>();
+    }
     c->finalized = false;
-    return car_finalize_weights(c);
+    return car_finalize_weights(c);       // names / shapes are checked against the config there: a missing image fails the import
+}
+extern "C" int car_import_packed(car_ctx* c, const char* path) {
+    if (!c || !path) return -1;
+    try { return import_packed_impl(c, path); }
+    catch (const std::exception& ex) { c->err = std::string("car_import_packed: ") + ex.what(); return -1; }   // no C++ exception crosses the C ABI
 }
 
 // ------------------------------------------------------------------------------------- small host-side tables
@@ -1151,9 +1176,9 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
 
     // ---- buffers
     const size_t kv_layer = (size_t)b * Hn * SA * 64;
-    const void* kv_before = c->kv.p;
+    const size_t kv_cap_before = c->kv.cap;        // ensure() never shrinks: a changed capacity IS a new allocation (the address may repeat)
     NEED(c, c->kv, (size_t)g.n_layer * 2 * kv_layer * e);
-    const bool kv_fresh = c->kv.p != kv_before;
+    const bool kv_fresh = c->kv.cap != kv_cap_before;
     const long rowsP = (long)b * T;
     NEED(c, c->ws[0], (size_t)b * T * g.caption_dim * e);                     // text input (cond | uncond)
     NEED(c, c->ws[1], (size_t)rowsP * D * e);                                 // h (prefill)

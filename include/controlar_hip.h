@@ -91,6 +91,7 @@ int  car_create(car_ctx** out, const car_config* cfg);
 void car_destroy(car_ctx* ctx);
 const char* car_last_error(const car_ctx* ctx);   /* also valid with ctx == NULL after a failed car_create */
 int  car_abi_version(void);
+const char* car_build_id(void);                   /* hash of the library sources: packed-weight cache files are valid for ONE build */
 
 /*
  * Weight loading — keyed by the reference state_dict names (SURVEY.md §8b "Weight contract"):

@@ -10,6 +10,10 @@ from controlar_amd import config as C, synth
 from controlar_amd import checkpoint as CK
 
 
+class _Foreign:                   # something the weights-only unpickler has no business building
+    pass
+
+
 @pytest.fixture(scope="module")
 def tiny():
     cfg = C.tiny_t2i(64, "canny")
@@ -36,6 +40,26 @@ def test_file_formats_follow_the_reference_rules(tiny, tmp_path):
     v = str(tmp_path / "vq.pt")
     torch.save({"model": vsd}, v)                                     # sample_t2i.py:48-49
     assert all(torch.equal(CK.load_checkpoint(v, vq=True)[k], vsd[k]) for k in vsd)
+
+
+def test_training_script_checkpoints_load(tiny, tmp_path):
+    """The .pt files the reference's own training loops write hold an argparse.Namespace and the optimizer state next to the
+    weights (train_t2i_canny.py:208, train_c2i_depth.py:252): the weights-only loader must accept them."""
+    import argparse
+    import pickle
+    cfg, gsd, vsd = tiny
+    opt = {"state": {0: {"step": torch.tensor(3.0), "exp_avg": torch.zeros(4)}}, "param_groups": [{"lr": 1e-4, "betas": (0.9, 0.95), "params": [0]}]}
+    p = str(tmp_path / "0001000.pt")
+    torch.save({"model": gsd, "optimizer": opt, "steps": 1000, "args": argparse.Namespace(gpt_model="GPT-XL", image_size=512, lr=1e-4)}, p)
+    got = CK.load_checkpoint(p)
+    assert set(got) == set(gsd) and all(torch.equal(got[k], gsd[k]) for k in gsd)
+
+    q = str(tmp_path / "foreign.pt")
+    torch.save({"model": gsd, "extra": _Foreign()}, q)
+    with pytest.raises(pickle.UnpicklingError):
+        CK.load_checkpoint(q)
+    got = CK.load_checkpoint(q, trust_pickle=True)         # explicit opt-in -> full pickle
+    assert all(torch.equal(got[k], gsd[k]) for k in gsd)
 
 
 def test_expected_keys_match_the_synthetic_reference_state_dicts(tiny):

@@ -86,3 +86,49 @@ def test_demo_process_edge_and_depth_end_to_end():
     assert len(d) == 2 and set(np.unique(np.array(d[0]))) <= {0, 255}
     with pytest.raises(RuntimeError):
         m.process_edge(ctrl, feats, 4.0, 1.0, 2000, 1.0, 3, 100, 200, 0.6, "Hed")       # extractor not injected
+
+
+def test_corrupt_or_foreign_cache_files_are_refused_and_the_loader_falls_back(tmp_path):
+    """car_import_packed validates everything it reads (sizes against the file and against numel, the build id in the header)
+    before touching the context; a refused file makes load_engine_from_checkpoints fall back to a normal load and rewrite it."""
+    import struct
+    from safetensors.torch import save_file
+    from controlar_amd.checkpoint import load_engine_from_checkpoints
+    from controlar_amd.engine import Engine
+    from tests.cases import load_case
+    cs = load_case("tiny_canny_cfg1")
+    gp = str(tmp_path / "gpt.safetensors")
+    save_file({k: v.contiguous() for k, v in cs["gsd"].items()}, gp)
+    cdir = str(tmp_path / "cache")
+    eng = Engine(cs["cfg"], "bf16")
+    info = load_engine_from_checkpoints(eng, gp, None, cache_dir=cdir)
+    assert info["cache"] == "miss"
+    eng.close()
+    good = open(info["file"], "rb").read()
+    hdr = 8 + 48 + len(bytes(eng._cc)) + 8                    # magic, build id, car_config, entry count
+    # first entry: kind u32, name_len u32, name, ndim u32, shape i64 x ndim, numel i64, bytes u64, payload
+    nl = struct.unpack_from("<I", good, hdr + 4)[0]
+    nd = struct.unpack_from("<I", good, hdr + 8 + nl)[0]
+    off_bytes = hdr + 8 + nl + 4 + 8 * nd + 8
+    cases = {
+        "truncated": good[: len(good) // 2],
+        "huge_size": good[:off_bytes] + struct.pack("<Q", 1 << 60) + good[off_bytes + 8:],
+        "size_not_numel": good[:off_bytes] + struct.pack("<Q", struct.unpack_from("<Q", good, off_bytes)[0] - 2) + good[off_bytes + 8:],
+        "other_build": good[:8] + b"0" * 40 + good[48:],
+        "entry_count": good[:hdr - 8] + struct.pack("<Q", 1 << 40) + good[hdr:],
+    }
+    for name, blob in cases.items():
+        bad = str(tmp_path / f"{name}.carpk")
+        open(bad, "wb").write(blob)
+        e2 = Engine(cs["cfg"], "bf16")
+        assert e2.lib.car_import_packed(e2._h, bad.encode()) != 0, name
+        assert b"car_import_packed" in e2.lib.car_last_error(e2._h), name
+        e2.close()
+    open(info["file"], "wb").write(cases["huge_size"])            # the cache entry itself goes bad: fall back, rewrite, then hit again
+    for expect in ("miss", "hit"):
+        e3 = Engine(cs["cfg"], "bf16")
+        assert load_engine_from_checkpoints(e3, gp, None, cache_dir=cdir)["cache"] == expect
+        e3.encode_control(cs["img"].cuda())
+        t = e3.generate(cs["emb"].cuda(), cs["n_new"], cs["mask"].cuda(), cfg_scale=1.0)
+        assert t.shape == (cs["img"].shape[0], cs["n_new"])
+        e3.close()

@@ -70,3 +70,30 @@ def test_t5_config_from_hf_rejects_relu():
     d["feed_forward_proj"] = "relu"
     with pytest.raises(ValueError):
         t5_config_from_hf(d)
+
+
+def test_t5embedder_keeps_the_reference_keywords_and_never_cleans_silently(tmp_path):
+    """language/t5.py:19-35,81-88: the constructor keywords of the reference, the local_cache path rule, and the text cleaning
+    default.  ftfy / bs4 are absent from this image, so the reference's clean_caption cannot be borrowed: asking for it must raise."""
+    import inspect
+    from controlar_amd.t5 import T5Embedder
+    ref_kw = ["device", "dir_or_name", "local_cache", "cache_dir", "hf_token", "use_text_preprocessing", "t5_model_kwargs", "torch_dtype",
+              "use_offload_folder", "model_max_length"]
+    sig = inspect.signature(T5Embedder.__init__)
+    assert all(k in sig.parameters for k in ref_kw)
+    assert sig.parameters["use_text_preprocessing"].default is True and sig.parameters["local_cache"].default is False
+    assert not any(p.kind is inspect.Parameter.VAR_KEYWORD for p in sig.parameters.values())      # nothing is swallowed
+    # lower().strip() branch and a user-supplied cleaner
+    assert T5Embedder._resolve_preprocessing(False, None)("  A Cat. ") == "a cat."
+    assert T5Embedder._resolve_preprocessing(True, lambda t: t.upper())("x") == "X"
+    try:
+        import ftfy, bs4  # noqa: F401
+        have = True
+    except ImportError:
+        have = False
+    if not have:
+        with pytest.raises(RuntimeError, match="clean_caption"):
+            T5Embedder._resolve_preprocessing(True, None)
+    # local_cache: the directory is cache_dir/dir_or_name (it does not exist -> the loader names exactly that path)
+    with pytest.raises(FileNotFoundError, match=str(tmp_path / "flan-t5-xl")):
+        T5Embedder("cpu", local_cache=True, cache_dir=str(tmp_path), dir_or_name="flan-t5-xl", use_text_preprocessing=False)

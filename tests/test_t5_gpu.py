@@ -115,7 +115,7 @@ def test_embedder_feeds_generate_like_the_sampler():
                 ids[i, : len(w)] = torch.tensor(w); m[i, : len(w)] = 1
             return {"input_ids": ids, "attention_mask": m}
 
-    emb = T5Embedder("cuda", config=cfg, state_dict=synth.t5_state_dict(cfg), tokenizer=Tok(), torch_dtype=torch.bfloat16)
+    emb = T5Embedder("cuda", config=cfg, state_dict=synth.t5_state_dict(cfg), tokenizer=Tok(), torch_dtype=torch.bfloat16, use_text_preprocessing=False)
     e, m = emb.get_text_embeddings(["A Quiet  Harbor at dawn ", "two cats"])
     assert e.shape == (2, 120, cfg.d_model) and e.dtype == torch.bfloat16 and m.shape == (2, 120) and m.sum().item() == 6 + 3
     c, cm = left_pad_caption(e, m)
