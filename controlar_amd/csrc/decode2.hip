@@ -378,7 +378,7 @@ extern "C" int car_pick_gemm_cfg(int M, int N, int K, int epi) {
     else if (Mb >= 6) cfg = hugeN ? 440 : (wideN ? 441 : (smallNK ? 110 : 221));
     else if (Mb >= 3) cfg = hugeN ? 441 : (wideN ? 241 : (longK ? 211 : 110));
     else if (Mb == 2) cfg = hugeN ? 421 : (wideN ? 221 : (longK ? 121 : 120));
-    else cfg = hugeN ? 411 : (wideN ? 211 : ((longK || smallNK) ? 111 : 110));
+    else cfg = hugeN ? 411 : (wideN ? 211 : 111);     // one m-block: 8 waves per tile everywhere (more bytes in flight per CU; one prologue-norm row per wave up to 8 rows)
     int I = cfg / 100;
     if (epi == EPI_SWIGLU && I < 2) I = 2;
     while (I > 1 && N % (16 * I)) I >>= 1;
@@ -593,6 +593,12 @@ extern "C" void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, in
         case 20: hipLaunchKernelGGL((dec_attn2_kernel<2, 0>), g, dim3(128), sh, st, *p); break;
         case 21: hipLaunchKernelGGL((dec_attn2_kernel<2, 1>), g, dim3(128), sh, st, *p); break;
         case 40: hipLaunchKernelGGL((dec_attn2_kernel<4, 0>), g, dim3(256), sh, st, *p); break;
+        // 8 / 16 waves per (sequence, head): the small-batch form — with a handful of sequences ONE launch without split-KV partials and
+        // without the combine kernel beats nsplit x 4 waves + combine (one dependent kernel less per layer, experiments/small_chain)
+        case 80: hipLaunchKernelGGL((dec_attn2_kernel<8, 0>), g, dim3(512), sh, st, *p); break;
+        case 81: hipLaunchKernelGGL((dec_attn2_kernel<8, 1>), g, dim3(512), sh, st, *p); break;
+        case 160: hipLaunchKernelGGL((dec_attn2_kernel<16, 0>), g, dim3(1024), sh, st, *p); break;
+        case 161: hipLaunchKernelGGL((dec_attn2_kernel<16, 1>), g, dim3(1024), sh, st, *p); break;
         default: hipLaunchKernelGGL((dec_attn2_kernel<4, 1>), g, dim3(256), sh, st, *p); break;
     }
     if (p->nsplit > 1 && p->out)

@@ -1000,11 +1000,14 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         ++nk;
     };
     GemmDP z; memset(&z, 0, sizeof(z));
-    // tiny chains (<= 4 rows): the latency-bound regime (BASELINE configs 2, 4).  The two RMSNorms of a layer and the final norm run
-    // in the prologue of the GEMM that consumes them (dec_gemm NORM variant): 6 kernels per layer instead of 8.  Measured on MI355X
-    // (profiles/r02_small_batch.txt): 1.55 -> 1.51 ms/step at 2 rows, but SLOWER from 8 rows up (every workgroup repeats the norm of
-    // all rows: 1.60 -> 1.67 ms at 8, 1.69 -> 2.07 ms at 16) — the step is bound by per-kernel latency chains, not by kernel count.
-    const bool fuse_norm = b <= 4 && D <= 2048 && !getenv("CAR_NO_SMALL_FUSE");
+    // tiny chains (<= 8 rows): the latency-bound regime (BASELINE configs 2, 4, 5).  The two RMSNorms of a layer and the final norm run
+    // in the prologue of the GEMM that consumes them (dec_gemm NORM variant), and the attention is ONE launch of 16-wave workgroups
+    // (no split-KV partials, no combine kernel): 5 dependent kernels per layer instead of 8.  Measured on MI355X with the layer loop of
+    // experiments/small_chain (profiles/r03_small_chain.txt, position 631, us per layer): 2 rows 40.2 -> 35.2, 4 rows 41.6 -> 35.7,
+    // 8 rows 47.8 -> 37.4 with 8-wave tiles (one row of the prologue norm per wave); from 12 rows up the fused prologue (every workgroup
+    // repeats the norm of all rows) no longer wins (44.1 either way at 12, 50.1 vs 49.4 at 16) and the separate norm kernels stay.
+    // The floor of this structure is the kernel boundary itself: 5 EMPTY kernels per layer cost 8.3 us.
+    const bool fuse_norm = b <= 8 && D <= 2048 && !getenv("CAR_NO_SMALL_FUSE");
     bf16_t* hc = h;                                                  // the residual stream; ping-pongs with `halt` when a control token is added
     bf16_t* halt = (bf16_t*)sb.xn + (size_t)b0 * D;                  // (the prefill's xn buffer is idle during decode)
     auto norm_fields = [&](GemmDP& q, const std::string& wname, int l, bool first_of_layer) {
@@ -1349,9 +1352,14 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             gr.b0 = mult * img0[gi]; gr.bg = mult * (img0[gi + 1] - img0[gi]);
             const int bg = gr.bg; const size_t M16 = rup((size_t)bg, 16);
             gr.nsplit = 1; { const int wg = bg * Hn; while (wg * gr.nsplit < 1024 && gr.nsplit < 16) gr.nsplit *= 2; }
+            // a handful of sequences (<= 240 (sequence, head) pairs = 12 XL sequences): ONE launch of 16-wave workgroups instead of split-KV + combine —
+            // one dependent kernel less per layer.  tools/small_ab.py on MI355X (XL, 1024 tokens, ms per step, same process): 2 rows 1.548 -> 1.406,
+            // 8 rows 1.611 -> 1.465, 12 rows 1.887 -> 1.725; at 16 rows the split form wins again (1.890 vs 1.923)  [profiles/r03_small_ab.txt]
+            const bool one_launch = (long)bg * Hn <= 240 && !getenv("CAR_ATTN_SPLIT_SMALL");
+            if (one_launch) gr.nsplit = 1;
             { const char* ev = getenv("CAR_ATTN_NSPLIT"); if (ev) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) gr.nsplit = v; } }   // A/B knob: shorter attention workgroups
-            // attention variant (decode2.hip; profiles/r02_kbench_*): 4 waves per (sequence, head) from 128 sequences up, 2 below
-            gr.attn_variant = (gr.nsplit == 1 && bg < 128) ? 20 : 40; gr.attn_lds_pad = 0;
+            // attention variant (decode2.hip; profiles/r02_kbench_*): 4 waves per (sequence, head) from 128 sequences up, 2 below; 16 in the one-launch small form
+            gr.attn_variant = (one_launch && gr.nsplit == 1) ? 160 : ((gr.nsplit == 1 && bg < 128) ? 20 : 40); gr.attn_lds_pad = 0;
             { const char* ev = getenv("CAR_ATTN_VARIANT"); if (ev) gr.attn_variant = atoi(ev); ev = getenv("CAR_ATTN_LDS_PAD"); if (ev) gr.attn_lds_pad = atoi(ev); }
             // persistent attention grid: R resident workgroups per CU walk the (sequence, head) items in equal shares
             gr.attn_pgrid = 0;

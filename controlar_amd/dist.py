@@ -1,12 +1,43 @@
 """Data-parallel edges of the path.  The reference shards images across ranks with
 no collective inside generation (autoregressive/sample/sample_t2i_ddp.py:127-170, index
-i*world+rank at :131); north_star adds ONE broadcast of text/control inputs before generation
-and a gather of tokens after it.  On ROCm backend "nccl" is RCCL (xGMI); the same code runs on
-gloo for the CPU tests.  `dist` may be None (single process): every function degrades to a no-op.
+i*world+rank at :131); north_star adds the distribution of text/control inputs from the rank that owns
+them before generation and a gather of tokens after it.  Two forms of the input edge:
+  * scatter_inputs  — rank `src` builds ONE shard at a time and sends it point-to-point to its rank: (W-1)/W of the global batch
+                      crosses xGMI once, and `src` never holds more than one shard (bench.py's default);
+  * broadcast_inputs — everyone receives the whole global batch in one packed broadcast and slices its shard: the right form for a
+                      1-GPU-sized batch (tens of MB, latency-bound), W-1 times the bytes for a large one.
+On ROCm backend "nccl" is RCCL (xGMI); the same code runs on gloo for the CPU tests.  `dist` may be None (single process):
+every function degrades to a no-op.
 """
 from __future__ import annotations
 
+import os
+import socket
+import sys
+
 import torch
+
+
+def respawn_command(script: str, argv, gpus: int, port: int | None = None):
+    """The command line that runs `script argv...` as `gpus` ranks of ONE node, one process per GPU, rendezvous on 127.0.0.1 (the container
+    hostname may not resolve) — what the driver itself runs for N > 1."""
+    if port is None:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(script)] + list(argv)
+
+
+def respawn_under_torchrun(script: str, argv, gpus: int) -> None:
+    """`script --gpus N` started as a plain process (no WORLD_SIZE in the environment) with N > 1: replace this process by
+    `python -m torch.distributed.run ... script argv` so that N ranks run and rank 0 prints the result.  Returns only when no respawn is needed."""
+    if gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL / device-tensor sharing across processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(gpus, 1))))
+    cmd = respawn_command(script, argv, gpus)
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
 
 
 def shard_slice(G: int, world: int, rank: int) -> slice:
@@ -65,6 +96,38 @@ def broadcast_inputs(dist, device, rank: int, G: int, H: int, W: int, T: int, ca
         for o in range(0, total, BCAST_CHUNK):
             dist.broadcast(buf[o:o + BCAST_CHUNK], src=src)
     return packed_views(buf, G, H, W, T, cap)
+
+
+def scatter_inputs(dist, device, rank: int, world: int, n_local: int, H: int, W: int, T: int, cap: int, make_shard, src: int = 0):
+    """Rank `src` owns the inputs (the serving front-end: T5 features + control maps).  For every destination rank r it calls
+    `make_shard(r)` -> (packed uint8 host buffer, or the (img, emb, mask) triple) of THAT rank's n_local images, copies it to the
+    device and sends it point-to-point (<= 1 GiB slices); its own shard is kept.  Returns the local (img, emb, mask) views.
+    Wire bytes: (W-1) shards, once — against (W-1) x W shards for broadcast-then-slice."""
+    total = sum(packed_layout(n_local, H, W, T, cap))
+    multi = dist is not None and dist.is_initialized() and world > 1
+
+    def to_packed(x):
+        if isinstance(x, torch.Tensor):
+            assert x.dtype == torch.uint8 and x.numel() == total
+            return x
+        img, emb, mask = x
+        return torch.cat([img.contiguous().view(torch.uint8).reshape(-1), emb.contiguous().view(torch.uint8).reshape(-1),
+                          mask.contiguous().view(torch.uint8).reshape(-1)])
+    mine = torch.empty(total, dtype=torch.uint8, device=device)
+    if rank == src:
+        stage = torch.empty(total, dtype=torch.uint8, device=device) if multi else None
+        for r in range(world):
+            host = to_packed(make_shard(r))
+            dst = mine if r == src else stage
+            for o in range(0, total, BCAST_CHUNK):
+                dst[o:o + BCAST_CHUNK].copy_(host[o:o + BCAST_CHUNK])
+            if r != src:
+                for o in range(0, total, BCAST_CHUNK):
+                    dist.send(stage[o:o + BCAST_CHUNK], dst=r)
+    elif multi:
+        for o in range(0, total, BCAST_CHUNK):
+            dist.recv(mine[o:o + BCAST_CHUNK], src=src)
+    return packed_views(mine, n_local, H, W, T, cap)
 
 
 def gather_tokens(dist, local_tokens: torch.Tensor) -> torch.Tensor:

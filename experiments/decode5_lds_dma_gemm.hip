@@ -1,4 +1,4 @@
-// decode3.hip — the decode linears of a LARGE chain (>= 256 rows: the 768-sequence bench step) as an LDS-tiled MFMA GEMM.
+// experiments/decode5_lds_dma_gemm.hip (EXPERIMENT, not product) — the decode linears of a LARGE chain (>= 256 rows: the 768-sequence bench step) as an LDS-tiled MFMA GEMM.
 //
 // dec_gemm (decode2.hip) gives every wave its own K slice and its own copy of the operands: right for <= 64 rows, where the step is
 // bound by weight bytes, but at 384 / 768 rows every weight chunk is re-fetched from L2 by M/64 workgroups and every X chunk by N/32,
@@ -18,76 +18,105 @@
 #include "car_common.h"
 
 #ifndef CAR_GEMMDP_DEFINED
-#error "decode3.hip is compiled as part of decode2.hip (GemmDP, the EPI_* constants and pack_bf16x2 come from there)"
+#error "include controlar_amd/csrc/decode2.hip first (GemmDP, the EPI_* constants and pack_bf16x2 come from there)"
 #endif
 
 typedef __attribute__((address_space(1))) const void d3_gptr_t;
 typedef __attribute__((address_space(3))) void d3_lptr_t;
 
-template <int NI, int MJ, int EPI>
-__global__ __launch_bounds__(256) void dec_gemm_lds_kernel(GemmDP p) {
+template <int WN, int WM, int NI, int MJ, int NS, int EPI>
+__global__ __launch_bounds__(64 * WN * WM) void dec_gemm_lds_kernel(GemmDP p) {
     constexpr int KS = 2;                          // k-blocks per stage
-    constexpr int NW = 2 * NI, NX = 2 * MJ;        // weight row-blocks / m-blocks of the workgroup tile
+    constexpr int NWAVE = WN * WM;
+    constexpr int NW = WN * NI, NX = WM * MJ;      // weight row-blocks / m-blocks of the workgroup tile
     constexpr int ROWC = NW + NX;                  // chunks per k-block
     constexpr int CH = ROWC * KS;                  // chunks per stage
-    constexpr int LPW = CH / 4;                    // DMA pieces per wave per stage
-    constexpr int NS = 3;
-    static_assert(CH % 4 == 0 && NI % 2 == 0, "tile shape");
+    constexpr int LPW = CH / NWAVE;                // DMA pieces per wave per stage
+    constexpr int AHEAD = NS - 1;                  // stages issued ahead of the one being consumed
+    static_assert(CH % NWAVE == 0 && NI % 2 == 0 && NS >= 3, "tile shape");
     extern __shared__ __attribute__((aligned(16))) u32x4 d3_lds[];            // [NS][CH][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 1, wm = wave >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % WN, wm = wave / WN;
     const int nkb = p.K >> 5, Mb = (p.M + 15) >> 4, nk = nkb / KS;
     const int MT = (Mb + NX - 1) / NX;
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of tiles so that the m-tiles
-    // sharing a weight row-block run on the same L2
+    // sharing a weight row-block run on the same L2 (bijective for any grid size)
     int t = blockIdx.x; const int total = gridDim.x;
     { const int x = t & 7, q = total >> 3, r = total & 7; t = x * q + (x < r ? x : r) + (t >> 3); }
     const int nt = t / MT, mt = t - nt * MT;
     const int rb0 = nt * NW, mb0 = mt * NX;
 
-    // this wave's DMA pieces of a stage: chunk c = wave + 4u = (ks, r); r < NW: weight row-block rb0 + r, else X m-block (clamped: rows
+    // this wave's DMA pieces of a stage: chunk c = wave + NWAVE·u = (ks, r); r < NW: weight row-block rb0 + r, else X m-block (clamped: rows
     // beyond the last m-block re-read it and are dropped in the epilogue)
-    const char* src[LPW]; int dks[LPW];
+    const char* src[LPW];
 #pragma unroll
     for (int u = 0; u < LPW; ++u) {
-        const int c = wave + 4 * u, ks = c / ROWC, r = c - ks * ROWC;
-        dks[u] = ks;
+        const int c = wave + NWAVE * u, ks = c / ROWC, r = c - ks * ROWC;
         if (r < NW) src[u] = (const char*)p.W + ((long)(rb0 + r) * nkb + ks) * 1024 + lane * 16;
         else { int mb = mb0 + (r - NW); mb = mb < Mb ? mb : Mb - 1; src[u] = (const char*)p.X + ((long)mb * nkb + ks) * 1024 + lane * 16; }
     }
-    auto issue = [&](int buf, int kt) {
+    int k_issue = 0;                               // k-stage of the next issue
+    auto issue = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < LPW; ++u)
-            __builtin_amdgcn_global_load_lds((d3_gptr_t*)(src[u] + (long)kt * (KS * 1024)), (d3_lptr_t*)(d3_lds + (size_t)(buf * CH + wave + 4 * u) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((d3_gptr_t*)(src[u] + (long)k_issue * (KS * 1024)), (d3_lptr_t*)(d3_lds + (size_t)(buf * CH + wave + NWAVE * u) * 64), 16, 0, 0);
+        ++k_issue;
     };
     f32x4 acc[NI][MJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto frags = [&](u32x4 (&a)[NI], u32x4 (&x)[MJ], int buf, int ks) {
+        const u32x4* base = d3_lds + ((size_t)buf * CH + (size_t)ks * ROWC) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i] = base[(wn * NI + i) * 64];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) x[j] = base[(NW + wm * MJ + j) * 64];
+    };
+    auto mma = [&](const u32x4 (&a)[NI], const u32x4 (&x)[MJ]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a[i], *(const bf16x8*)&x[j], acc[i][j], 0, 0, 0);
+    };
+    // wait until this wave's pieces of the OLDEST outstanding stage have landed, `younger` later stages may stay in flight
+    auto wait_oldest = [&](int younger) {
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPW) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
 
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
+    // Software pipeline.  Registers hold the fragments of ONE k-block ahead of the MFMAs; the DMA ring holds AHEAD stages ahead of the reads:
+    //   iteration kt:  [ds_read (kt, k-block 1)] [MFMA (kt, k-block 0)] [vmcnt: stage kt+1 landed] [s_barrier] [DMA issue: stage kt+AHEAD -> the buffer of
+    //                  stage kt-1, whose last fragments every wave consumed before this barrier] [ds_read (kt+1, k-block 0)] [MFMA (kt, k-block 1)]
+    // A staged buffer is read only after the counted vmcnt of every issuing wave AND a barrier the reader has passed (cdna_hip_programming.md §5).
+#pragma unroll
+    for (int s_ = 0; s_ < AHEAD; ++s_) if (s_ < nk) issue(s_);
+    { const int issued = nk < AHEAD ? nk : AHEAD; wait_oldest(issued - 1); }
+    __builtin_amdgcn_s_barrier();
+    u32x4 a0[NI], x0[MJ], a1[NI], x1[MJ];
+    frags(a0, x0, 0, 0);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        // this wave's pieces of stage kt have landed (stage kt+1 may stay in flight) ...
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();              // ... so have the other waves'; and everyone is done reading the stage consumed at kt-1
-        if (kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NS - 1, kt + 2);
-        const u32x4* base = d3_lds + (size_t)buf * CH * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 a[NI], x[MJ];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) a[i] = base[(ks * ROWC + wn * NI + i) * 64];
-#pragma unroll
-            for (int j = 0; j < MJ; ++j) x[j] = base[(ks * ROWC + NW + wm * MJ + j) * 64];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < MJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a[i], *(const bf16x8*)&x[j], acc[i][j], 0, 0, 0);
+        frags(a1, x1, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nbuf = buf + 1 == NS ? 0 : buf + 1;
+        if (kt + 1 < nk) {
+            // outstanding DMA stages now: kt+1 .. min(kt+AHEAD-1, nk-1)
+            const int last = kt + AHEAD - 1 < nk - 1 ? kt + AHEAD - 1 : nk - 1;
+            wait_oldest(last - (kt + 1));
+            __builtin_amdgcn_s_barrier();
+            if (k_issue < nk) issue(buf >= 1 ? buf - 1 : NS - 1);
+            frags(a0, x0, nbuf, 0);
         }
-        buf = buf + 1 == NS ? 0 : buf + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
     }
 
     // ---- epilogue: the units of dec_gemm_kernel (pair of adjacent row-blocks x m-block), arithmetic and reference lines as decode2.hip
@@ -164,31 +193,35 @@ __global__ __launch_bounds__(256) void dec_gemm_lds_kernel(GemmDP p) {
     }
 }
 
-template <int NI, int MJ>
+template <int WN, int WM, int NI, int MJ, int NS>
 static int launch_gemm_lds(const GemmDP& p, int epi, hipStream_t st) {
-    const int Mb = (p.M + 15) / 16, MT = (Mb + 2 * MJ - 1) / (2 * MJ), NT = p.N / (32 * NI);
-    const dim3 g(NT * MT), b(256);
-    constexpr size_t sh = (size_t)3 * 2 * (2 * NI + 2 * MJ) * 1024;
+    const int Mb = (p.M + 15) / 16, MT = (Mb + WM * MJ - 1) / (WM * MJ), NT = p.N / (16 * WN * NI);
+    const dim3 g(NT * MT), b(64 * WN * WM);
+    constexpr size_t sh = (size_t)NS * 2 * (WN * NI + WM * MJ) * 1024;
 #define LT(E)                                                                                                                     \
     do {                                                                                                                          \
         static bool attr = false;                                                                                                 \
-        if (sh > 48 * 1024 && !attr) { (void)hipFuncSetAttribute((const void*)dec_gemm_lds_kernel<NI, MJ, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
-        hipLaunchKernelGGL((dec_gemm_lds_kernel<NI, MJ, E>), g, b, sh, st, p);                                                     \
+        if (sh > 48 * 1024 && !attr) { (void)hipFuncSetAttribute((const void*)dec_gemm_lds_kernel<WN, WM, NI, MJ, NS, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
+        hipLaunchKernelGGL((dec_gemm_lds_kernel<WN, WM, NI, MJ, NS, E>), g, b, sh, st, p);                                         \
     } while (0)
     if (epi == EPI_LOGITS) LT(EPI_LOGITS); else if (epi == EPI_RESID) LT(EPI_RESID); else if (epi == EPI_SWIGLU) LT(EPI_SWIGLU); else LT(EPI_QKV);
 #undef LT
     return 0;
 }
 
-// cfg = NI*10 + MJ: workgroup tile (32·NI) weight rows x (32·MJ) batch rows.  -1 = outside the domain (the caller falls back to dec_gemm).
+// cfg: 1 = 128 x 128 tile, 8 waves (4 x 2, wave tile 32 x 64), 4 stages     2 = 128 x 128, 4 waves (2 x 2, wave tile 64 x 64), 4 stages
+//      3 = 64 x 64, 4 waves (2 x 2, wave tile 32 x 32), 5 stages             4 = 128 (n) x 64 (m), 8 waves (4 x 2, wave tile 32 x 32), 5 stages
+//      5 = 64 (n) x 128 (m), 8 waves (2 x 4, wave tile 32 x 32), 5 stages
+// -1 = outside the domain (the caller falls back to dec_gemm).
 extern "C" int car_launch_dec_gemm_lds(const GemmDP* p, int epi, int cfg, hipStream_t st) {
-    const int NI = cfg / 10;
-    if (p->wscale || p->nw || p->K % 64 || p->N % (32 * NI) || p->M < 1) return -1;      // bf16 weights, whole stages, no fused norm
+    const int tn = (cfg == 3 || cfg == 5) ? 64 : 128;
+    if (p->wscale || p->nw || p->K % 64 || p->N % tn || p->M < 1) return -1;      // bf16 weights, whole stages, no fused norm
     switch (cfg) {
-        case 22: return launch_gemm_lds<2, 2>(*p, epi, st);
-        case 24: return launch_gemm_lds<2, 4>(*p, epi, st);
-        case 42: return launch_gemm_lds<4, 2>(*p, epi, st);
-        case 44: return launch_gemm_lds<4, 4>(*p, epi, st);
+        case 1: return launch_gemm_lds<4, 2, 2, 4, 4>(*p, epi, st);
+        case 2: return launch_gemm_lds<2, 2, 4, 4, 4>(*p, epi, st);
+        case 3: return launch_gemm_lds<2, 2, 2, 2, 5>(*p, epi, st);
+        case 4: return launch_gemm_lds<4, 2, 2, 2, 5>(*p, epi, st);
+        case 5: return launch_gemm_lds<2, 4, 2, 2, 5>(*p, epi, st);
         default: return -1;
     }
 }

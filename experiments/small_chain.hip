@@ -48,24 +48,28 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const uint4* p, size_t n1
     if (acc == 0x9e3779b9u) *sink = acc;              // practically never: the store only defeats dead-code elimination
 }
 
+__global__ void empty_kernel(unsigned* sink) { if (sink == nullptr && threadIdx.x == 12345) *sink = 1; }
 static int g_prefetch_grid = 256;                     // 256 workgroups x 256 lanes x 8 x 16 B = 8 MB in flight
 
 struct Dims { int M, D, Fh, H, SA, T, pos; };
 struct Bufs { bf16_t *W, *kv, *h, *h2, *xn, *att, *mid, *q, *nw; float *part, *rope; int *dpos; unsigned* sink; size_t per_layer, kvper; };
 
-enum { V_BASE = 0, V_NOSPLIT = 1, V_W8 = 2, V_PREFETCH = 3, V_UNNORM = 4, V_PREFETCH_NOSPLIT = 5, V_LAT = 6, V_LAT_NOSPLIT = 7, NVAR = 8 };
+enum { V_BASE = 0, V_NOSPLIT = 1, V_W8 = 2, V_PREFETCH = 3, V_UNNORM = 4, V_PREFETCH_NOSPLIT = 5, V_LAT = 6, V_LAT_NOSPLIT = 7, V_NS8 = 8, V_NS16 = 9, V_NS16PF = 10, V_NS16_W8 = 11, V_SPLIT4 = 12, V_EMPTY = 13, V_UNNORM_NS16_W8 = 14, NVAR = 15 };
 static const char* VNAME[NVAR] = {"base (engine.hip today, 6 kernels/layer)", "nosplit attention (5 kernels/layer)", "8-wave linears", "prefetch next layer's weights (side branch)",
                                   "separate rmsnorm2 kernels (8 kernels/layer)", "prefetch + nosplit attention",
-                                  "linears with hoisted epilogue loads (decode2_lat.hip)", "hoisted epilogue loads + nosplit attention"};
+                                  "linears with hoisted epilogue loads (decode2_lat.hip)", "hoisted epilogue loads + nosplit attention",
+                                  "nosplit attention, 8 waves per (row, head)", "nosplit attention, 16 waves per (row, head)", "nosplit attention, 16 waves, prefetch form",
+                                  "nosplit 16 waves + 8-wave linears", "split-KV 4 (instead of 16) + combine", "FLOOR: 5 empty 256-workgroup kernels per layer", "separate rmsnorm2 + nosplit 16 waves + 8-wave linears (7 kernels)"};
 
 static void layer(const Dims& d, const Bufs& b, int l, int NL, int variant, hipStream_t st, hipStream_t side, hipEvent_t ef, hipEvent_t ej) {
     const int D = d.D, Fh = d.Fh, M = d.M;
+    if (variant == V_EMPTY) { for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, st, b.sink); return; }
     bf16_t* w = b.W + b.per_layer * (l % NL);
     bf16_t *wqkv = w, *wo = w + (size_t)3 * D * D, *w13 = wo + (size_t)D * D, *w2 = w13 + (size_t)2 * Fh * D;
     bf16_t* kc = b.kv + b.kvper * 2 * (l % NL); bf16_t* vc = kc + b.kvper;
-    const bool pre = variant == V_PREFETCH || variant == V_PREFETCH_NOSPLIT, nosplit = variant == V_NOSPLIT || variant == V_PREFETCH_NOSPLIT || variant == V_LAT_NOSPLIT;
+    const bool pre = variant == V_PREFETCH || variant == V_PREFETCH_NOSPLIT, nosplit = variant == V_NOSPLIT || variant == V_PREFETCH_NOSPLIT || variant == V_LAT_NOSPLIT || variant == V_NS8 || variant == V_NS16 || variant == V_NS16PF || variant == V_NS16_W8 || variant == V_UNNORM_NS16_W8;
     const bool lat = variant == V_LAT || variant == V_LAT_NOSPLIT;
-    const bool fuse = variant != V_UNNORM;
+    const bool fuse = variant != V_UNNORM && variant != V_UNNORM_NS16_W8;
     if (pre) {       // fork: run ahead on the NEXT layer's weights while this layer's six kernels wait on each other
         CK(hipEventRecord(ef, st)); CK(hipStreamWaitEvent(side, ef, 0));
         const bf16_t* nxt = b.W + b.per_layer * ((l + 1) % NL);
@@ -75,7 +79,7 @@ static void layer(const Dims& d, const Bufs& b, int l, int NL, int variant, hipS
     auto gemm = [&](const bf16_t* W, const bf16_t* X, int N, int K, int epi, GemmDP p) {
         p.W = W; p.X = X; p.M = M; p.N = N; p.K = K;
         int cfg = car_pick_gemm_cfg(M, N, K, epi);
-        if (variant == V_W8) cfg = (cfg / 10) * 10 + 1;
+        if (variant == V_W8 || variant == V_NS16_W8 || variant == V_UNNORM_NS16_W8) cfg = (cfg / 10) * 10 + 1;
         const int J = (cfg / 10) % 10, Mb = (M + 15) / 16; p.w_nt = (Mb + J - 1) / J == 1;
         if (lat ? car_launch_dec_gemm_lat_cfg(&p, epi, cfg, st) : car_launch_dec_gemm_cfg(&p, epi, cfg, st)) { printf("cfg %d rejected (N=%d K=%d)\n", cfg, N, K); exit(3); }
     };
@@ -89,8 +93,9 @@ static void layer(const Dims& d, const Bufs& b, int l, int NL, int variant, hipS
     {
         Attn2P a; memset(&a, 0, sizeof(a)); a.q = b.q; a.kc = kc; a.vc = vc; a.pos = b.dpos; a.out = b.att; a.part = b.part; a.H = d.H; a.SA = d.SA; a.T = d.T; a.dim = D; a.out_packed = 1;
         int ns = 1; while (M * d.H * ns < 1024 && ns < 16) ns *= 2;
-        a.nsplit = nosplit ? 1 : ns;
-        car_launch_dec_attn2_var(&a, M, nosplit ? 41 : 40, 0, st);
+        a.nsplit = nosplit ? 1 : (variant == V_SPLIT4 ? (ns < 4 ? ns : 4) : ns);
+        const int av = variant == V_NS8 ? 80 : ((variant == V_NS16 || variant == V_NS16_W8 || variant == V_UNNORM_NS16_W8) ? 160 : (variant == V_NS16PF ? 161 : (nosplit ? 41 : 40)));
+        car_launch_dec_attn2_var(&a, M, av, 0, st);
     }
     { GemmDP q = z; q.h = b.h; gemm(wo, b.att, D, D, EPI_RESID, q); }
     {
@@ -104,8 +109,9 @@ static void layer(const Dims& d, const Bufs& b, int l, int NL, int variant, hipS
 
 int main(int argc, char** argv) {
     Dims d; d.M = argc > 1 ? atoi(argv[1]) : 2; d.D = 1280; d.Fh = 3584; d.H = 20; d.T = 120; d.pos = argc > 2 ? atoi(argv[2]) : 631; d.SA = 1152;
-    const int NL = 12, REPS = 30;
+    int NL = 12; const int REPS = 30;
     if (argc > 3) g_prefetch_grid = atoi(argv[3]);
+    if (argc > 4) NL = atoi(argv[4]);          // 1: every layer re-reads the same 41.6 MB (Infinity-Cache resident) — isolates the HBM share of the per-kernel latency
     if (d.M < 1 || d.M > 16 || d.pos < 1 || d.pos >= d.SA) { printf("rows must be 1..16, pos 1..%d\n", d.SA - 1); return 2; }
     Bufs b; memset(&b, 0, sizeof(b));
     b.per_layer = (size_t)(3 * d.D * d.D + d.D * d.D + 2 * d.Fh * d.D + d.D * d.Fh);

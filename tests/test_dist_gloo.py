@@ -106,3 +106,81 @@ def test_timed_steps_contract_world2():
     assert n0 == 5 and n1 == 5 and out0 == (0, 5) and out1 == (1, 5)      # 2 warm-up + 3 timed calls each
     assert abs(e0 - e1) < 1e-9                                              # both ranks report the same (max) time
     assert 0.29 <= e0 <= 0.6                                                # = 3 x 0.10 s of the slow rank, not 3 x 0.05
+
+
+def _scatter_worker(rank, world, port, n_local, q):
+    import torch.distributed as dist
+    from controlar_amd import synth
+    import controlar_amd.dist as cdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H = W = 32; T, cap = 12, 64
+    cdist.BCAST_CHUNK = 4096                    # a shard goes out in slices, as a 1.6 GB one does in 1 GiB slices
+    built = []
+
+    def make_shard(r):                          # only the owner is ever asked; one shard at a time; the triple form is accepted too
+        built.append(r)
+        idx = [r + world * j for j in range(n_local)]
+        img = torch.stack([synth.canny_like_control(1, H, W, seed=1234 + g, dtype=torch.bfloat16)[0] for g in idx])
+        em = [synth.text_embeddings(1, T, cap, seed=1234 + g) for g in idx]
+        return img, torch.stack([e[0][0] for e in em]).to(torch.bfloat16), torch.stack([e[1][0] for e in em])
+    img, emb, mask = cdist.scatter_inputs(dist, torch.device("cpu"), rank, world, n_local, H, W, T, cap, make_shard)
+    local = (img.float().sum(dim=(1, 2, 3)).round().to(torch.int32)[:, None] + mask.sum(dim=1).to(torch.int32)[:, None] + torch.arange(5, dtype=torch.int32)[None])
+    allt = cdist.gather_tokens(dist, local)
+    q.put((rank, allt.clone(), emb.float().abs().sum().item(), list(built)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scatter_shards_gather_world2():
+    """bench.py's default input edge: rank 0 owns the inputs, builds ONE shard at a time and sends it point-to-point; every rank ends up with
+    exactly its strided shard (images r, r+W, ...), and the gathered tokens come back in global image order."""
+    from controlar_amd import synth
+    n_local, world = 3, 2
+    G = n_local * world
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_scatter_worker, args=(r, world, port, n_local, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in ps]
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    img = synth.canny_like_control(G, 32, 32).to(torch.bfloat16)
+    emb, mask = synth.text_embeddings(G, 12, 64)
+    want = (img.float().sum(dim=(1, 2, 3)).round().to(torch.int32)[:, None] + mask.sum(dim=1).to(torch.int32)[:, None] +
+            torch.arange(5, dtype=torch.int32)[None])
+    for rank, allt, esum, built in res:
+        assert torch.equal(allt, want), rank
+        assert built == ([0, 1] if rank == 0 else []), (rank, built)               # only the owner builds shards, in rank order
+        mine = emb[rank::world].to(torch.bfloat16).float().abs().sum().item()
+        assert abs(esum - mine) < 1e-3, rank                                        # each rank holds ITS shard, not the global batch
+
+
+def test_gpus_flag_respawns_under_torchrun():
+    """`script --gpus 2` started as a plain process (no WORLD_SIZE) must become two ranks by itself (bench.py's start-up): the probe
+    re-executes under `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1`, scatters, gathers, and rank 0
+    reports n_gpus = 2 with the tokens of all 6 images in global order."""
+    import json
+    import subprocess
+    import sys
+    from controlar_amd import synth
+    from controlar_amd.dist import respawn_command
+    cmd = respawn_command("bench.py", ["--gpus", "4", "--steps", "3"], 4, port=29999)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_spawn_probe.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, probe, "--gpus", "2", "--batch", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["master"] == "127.0.0.1"
+    G = 6
+    img = synth.canny_like_control(G, 32, 32).to(torch.bfloat16)
+    _, mask = synth.text_embeddings(G, 12, 64)
+    want = (img.float().sum(dim=(1, 2, 3)).round().to(torch.int32)[:, None] + mask.sum(dim=1).to(torch.int32)[:, None] + torch.arange(4, dtype=torch.int32)[None])
+    assert rec["tokens"] == want.tolist()
+    # --gpus 1, or an environment that already carries WORLD_SIZE (the driver's torchrun launch): no respawn
+    out1 = subprocess.run([sys.executable, probe, "--gpus", "1", "--batch", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert out1.returncode == 0 and json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 1
