@@ -10,11 +10,12 @@ with inputs already resident in HBM when the timed region starts.
 
 Multi-GPU: pure data parallel, one process per GPU.  `--gpus N` started as a plain process re-executes
 itself under `python -m torch.distributed.run` (N ranks, 127.0.0.1 rendezvous); under torchrun the
-environment decides.  Rank 0 owns the inputs and sends every rank ITS shard of text embeddings + masks +
-control maps point-to-point over RCCL/xGMI (one shard built and sent at a time), each rank generates its
-shard (no collective inside the path), tokens are all-gathered at the end; both edges are timed and
-reported beside the metric.  `--input-dist local`: every rank draws its own shard (no input traffic at
-all — the reference's DDP sampler, sample_t2i_ddp.py:127-170).  weak scaling.
+environment decides.  Every rank draws its own strided shard of the global batch (per-image seeds: image g
+is the same for any N — the reference's DDP sampler, sample_t2i_ddp.py:127-170, has no input collective
+either), generates it with no collective inside the path, and the tokens are all-gathered over RCCL at the
+end (timed, reported).  `--input-dist scatter`: rank 0 owns the inputs (a serving front-end holding the T5
+features and control maps) and sends every rank ITS shard point-to-point over RCCL/xGMI, one shard built and
+sent at a time; timed and reported.  weak scaling.
 
 Prints ONE JSON line (rank 0) with `roofline` (decode step vs the HBM roofline, HIP-event
 timed inside the library on its own stream) and `cpu_baseline` (the CPU oracle, N=1 only).
@@ -48,9 +49,11 @@ def parse():
     ap.add_argument("--condition-type", default="canny", help="'canny'/'seg' -> nearest resize, anything else -> bicubic (dinov2_adapter.py:19-23)")
     ap.add_argument("--adapter-size", default="small", choices=["small", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--input-dist", default="scatter", choices=["scatter", "local"],
-                    help="N > 1: 'scatter' = rank 0 owns the inputs and sends each rank its shard over RCCL (timed, reported); "
-                         "'local' = every rank draws its own shard (same global batch: per-image seeds)")
+    ap.add_argument("--input-dist", default="local", choices=["scatter", "local"],
+                    help="N > 1: 'local' = every rank draws its own shard (per-image seeds: the same global batch for any N; no input traffic — the "
+                         "reference's DDP sampler); 'scatter' = rank 0 owns the inputs (serving front-end) and sends each rank its shard over RCCL, "
+                         "timed and reported.  Synthesis costs ~40 ms per image on the GPU box's host, so a rank-0-owned batch of 8 x 768 images "
+                         "takes minutes to draw before anything is sent: not the default")
     ap.add_argument("--overlap-vq", action="store_true",
                     help="run the VQ decode of batch i on a side stream under the token loop of batch i+1 (measured: no gain on MI355X — "
                          "the token loop is HBM-bound and the decoder's GEMM grids take every CU; kept for experiments)")
@@ -205,7 +208,8 @@ def main():
 
     def make_shard(r):
         packed, h_img, h_emb, h_mask = alloc_packed_host(args.batch, Hh, Ww, T, cap)
-        for j in range(args.batch):
+
+        def one(j):
             g_ = r + world * j                                # global image index of local image j on rank r
             if args.condition_type in ("canny", "seg"):
                 h_img[j] = synth.canny_like_control(1, Hh, Ww, seed=1234 + g_, dtype=torch.bfloat16)[0]             # {-1,+1}: exact in bf16
@@ -213,6 +217,8 @@ def main():
                 h_img[j] = synth.smooth_control(1, Hh, Ww, seed=1234 + g_)[0].to(torch.bfloat16)
             e_, m_ = synth.text_embeddings(1, T, cap, seed=1234 + g_)
             h_emb[j] = e_[0].to(torch.bfloat16); h_mask[j] = m_[0]
+        for j in range(args.batch):
+            one(j)
         return packed
     t_bc0 = time.perf_counter()
     if args.input_dist == "local" or world == 1:
