@@ -290,6 +290,8 @@ def main():
         parity["golden_prefix_tokens"] = int(neq[0]) if len(neq) else int(len(gold))
         parity["golden_token_agreement"] = float((mine == gold).mean())
         assert parity["golden_prefix_tokens"] >= 2, parity
+        if args.precision == "fp32":       # exact mode: the reference's greedy tokens, all of them, whatever the batch (batch-invariant kernels)
+            assert parity["golden_token_agreement"] == 1.0, parity
 
     # HBM traffic of one decode step (read + write) is taken from the committed PMC summary of the SAME configuration
     # (profiles/pmc_decode_step.json, written by tools/pmc_decode.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`

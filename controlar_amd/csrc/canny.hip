@@ -66,9 +66,12 @@ __global__ __launch_bounds__(256) void canny_grad_nms_kernel(const unsigned char
     }
 }
 
-__global__ __launch_bounds__(256) void canny_hyst_kernel(unsigned char* __restrict__ map, int H, int W, int* __restrict__ changed) {
+// One hysteresis sweep.  `prev` = the "something changed" flag of the previous sweep: once a sweep changes nothing the fixed point is reached and
+// every later sweep of the batch exits at once (engine.hip car_canny enqueues the sweeps in batches and looks at the LAST flag of a batch only).
+__global__ __launch_bounds__(256) void canny_hyst_kernel(unsigned char* __restrict__ map, int H, int W, const int* __restrict__ prev, int* __restrict__ changed) {
     __shared__ unsigned char t[CT + 2][CT + 2];
     __shared__ int again, any;
+    if (*prev == 0) return;
     const int b = blockIdx.z, x0 = blockIdx.x * CT, y0 = blockIdx.y * CT, tid = threadIdx.x;
     unsigned char* mp = map + (long)b * H * W;
     for (int i = tid; i < (CT + 2) * (CT + 2); i += 256) {
@@ -122,8 +125,8 @@ __global__ void canny_finish_kernel(const unsigned char* __restrict__ map, unsig
 extern "C" void car_launch_canny_grad_nms(const unsigned char* img, unsigned char* map, int B, int H, int W, int low, int high, hipStream_t st) {
     hipLaunchKernelGGL(canny_grad_nms_kernel, dim3((W + CT - 1) / CT, (H + CT - 1) / CT, B), dim3(256), 0, st, img, map, H, W, low, high);
 }
-extern "C" void car_launch_canny_hyst(unsigned char* map, int B, int H, int W, int* changed, hipStream_t st) {
-    hipLaunchKernelGGL(canny_hyst_kernel, dim3((W + CT - 1) / CT, (H + CT - 1) / CT, B), dim3(256), 0, st, map, H, W, changed);
+extern "C" void car_launch_canny_hyst(unsigned char* map, int B, int H, int W, const int* prev, int* changed, hipStream_t st) {
+    hipLaunchKernelGGL(canny_hyst_kernel, dim3((W + CT - 1) / CT, (H + CT - 1) / CT, B), dim3(256), 0, st, map, H, W, prev, changed);
 }
 extern "C" void car_launch_canny_finish(int mode, const unsigned char* map, unsigned char* edges, void* control, int B, long HW, hipStream_t st) {
     long n = B * HW; int g = (int)((n + 255) / 256); if (g > 4096) g = 4096;

@@ -66,7 +66,7 @@ void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st);
 void car_launch_build_mask(const int64_t* emb_mask, const int* row_img, unsigned char* out, int b, int T, hipStream_t st);
 // canny.hip
 void car_launch_canny_grad_nms(const unsigned char* img, unsigned char* map, int B, int H, int W, int low, int high, hipStream_t st);
-void car_launch_canny_hyst(unsigned char* map, int B, int H, int W, int* changed, hipStream_t st);
+void car_launch_canny_hyst(unsigned char* map, int B, int H, int W, const int* prev, int* changed, hipStream_t st);
 void car_launch_canny_finish(int mode, const unsigned char* map, unsigned char* edges, void* control, int B, long HW, hipStream_t st);
 // pack.hip
 void car_launch_rows_to_bf16(const void* src, int dtype, void* dst, long N, long K, int ileave, hipStream_t st);
@@ -105,6 +105,7 @@ void car_launch_advance(int* pos, int* step, hipStream_t st);
 void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st);
 void car_launch_dec_attn(int mode, const AttnP* p, int b, hipStream_t st);
 void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st);
+void car_launch_label_index(const int64_t* labels, const int* row_img, const int* row_unc, int num_classes, int* idx, int* err_flag, int b, hipStream_t st);
 void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, hipStream_t st);
 }
 
@@ -157,6 +158,7 @@ struct car_ctx {
     int dbg_skip = 0;
     int n_cu = 256;       // compute units of the device (persistent-grid sizing)
     DevBuf rowimg;       // [b] int: image index of each row
+    DevBuf rowunc, dev_flags; std::vector<int> h_rowunc;   // c2i: uncond-row marks (device + the host copy the async upload reads); sticky device error flags ([0] = class label out of range)
     DevBuf canny_map;    // car_canny: uint8 [B,H,W] candidate/edge map + the "changed" flag
     car_t5_config t5 = {}; bool has_t5 = false;
     DevBuf t5_in;        // int32 ids [B*T] | uint8 key mask [B*T] | staging for host-side int64 inputs
@@ -256,7 +258,7 @@ extern "C" void car_destroy(car_ctx* c) {
     for (auto& kv : c->resize_cache) { (void)hipFree(kv.second.iy); (void)hipFree(kv.second.ix); if (kv.second.wy) (void)hipFree(kv.second.wy); if (kv.second.wx) (void)hipFree(kv.second.wx); }
     if (c->rope) (void)hipFree(c->rope);
     c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
-    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release(); c->canny_map.release(); c->t5_in.release(); c->t5_bias.release();
+    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release(); c->rowunc.release(); c->dev_flags.release(); c->canny_map.release(); c->t5_in.release(); c->t5_bias.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
     (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 7; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); (void)hipEventDestroy(c->ev_phase[i]); }
@@ -1196,8 +1198,12 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     NEED(c, c->ws[7], (size_t)rowsP * (mode == CAR_BF16 ? Fh : 3 * Fh) * e);  // ffn mid (+ interleaved w13 out in exact mode)
     NEED(c, c->ws[8], (size_t)rowsP * D * e);                                 // attention out
     NEED(c, c->ws[9], (size_t)b * V * 4);                                     // logits fp32
-    int nsplit = 1;
-    { const int wg = b * Hn; while (wg * nsplit < 1024 && nsplit < 16) nsplit *= 2; }
+    // exact mode: ALWAYS 16 KV splits, whatever the batch — the split count fixes the order in which a row's softmax partial sums are folded, so a
+    // sequence decodes to the same bits in a batch of 1 and in a batch of 192 (every other exact-mode kernel already sums one fixed-order fp32
+    // chain per output).  Found by bench.py --precision fp32: with a batch-dependent split count row 0 left the reference's greedy tokens at
+    // token 488 of 1024 (a 1.2e-3 top-2 margin) at 192 images while a batch of 1 reproduced all 1024.
+    int nsplit = fast ? 1 : 16;
+    if (fast) { const int wg = b * Hn; while (wg * nsplit < 1024 && nsplit < 16) nsplit *= 2; }
     NEED(c, c->ws[10], (size_t)b * Hn * nsplit * 66 * 4);                     // split-KV partials
     NEED(c, c->ws[11], (size_t)B * (use_control ? n_tok : 1) * D * e);        // condition_mlp output / mlp mid
     NEED(c, c->scal, (size_t)(16 + 2 * b + 2) * 4 + sizeof(SampleDyn) + 16);
@@ -1235,19 +1241,15 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     void *text = c->ws[0].p, *h = c->ws[1].p, *xn = c->ws[2].p, *qkv = c->ws[3].p, *P = c->ws[5].p, *vT = c->ws[6].p, *mid = c->ws[7].p, *att = c->ws[8].p;
     float* S = (float*)c->ws[4].p; float* logits = (float*)c->ws[9].p;
     if (c2i) {
-        // LabelEmbedder (gpt.py:89-96): h[b] = embedding_table[label]; CFG rows use the null class num_classes (generate.py:141)
-        std::vector<int64_t> hl((size_t)B);
-        HIPCHK(c, hipStreamSynchronize(st));
-        HIPCHK(c, hipMemcpy(hl.data(), labels, (size_t)B * 8, hipMemcpyDeviceToHost));
-        std::vector<int> idx((size_t)b);
-        for (int i = 0; i < b; ++i) {
-            const int64_t l = row_unc[(size_t)i] ? (int64_t)g.num_classes : hl[(size_t)row_img[(size_t)i]];
-            if (l < 0 || l > g.num_classes) FAIL(c, "car_generate_c2i: class label %lld out of range [0,%d]", (long long)l, g.num_classes);
-            idx[(size_t)i] = (int)l;
-        }
+        // LabelEmbedder (gpt.py:89-96): h[b] = embedding_table[label]; CFG rows use the null class num_classes (generate.py:141).
+        // The row -> table-index map is built on the device (no host round trip): an out-of-range label is clamped to the null class and
+        // raises a sticky device flag that car_get_stats reports (the reference's nn.Embedding fails asynchronously on a GPU as well).
+        c->h_rowunc.assign(row_unc.begin(), row_unc.end());
+        NEED(c, c->rowunc, (size_t)b * 4 + 16);
+        if (!c->dev_flags.p) { NEED(c, c->dev_flags, 64); HIPCHK(c, hipMemsetAsync(c->dev_flags.p, 0, 64, st)); }
+        HIPCHK(c, hipMemcpyAsync(c->rowunc.p, c->h_rowunc.data(), (size_t)b * 4, hipMemcpyHostToDevice, st));
         int* didx = cur;       // cur_tok[b] is free until the prefill sampler writes it
-        HIPCHK(c, hipMemcpyAsync(didx, idx.data(), (size_t)b * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        car_launch_label_index(labels, (const int*)c->rowimg.p, (const int*)c->rowunc.p, g.num_classes, didx, (int*)c->dev_flags.p, b, st);
         car_launch_gather_rows(mode, Wp(c, "cls_embedding.embedding_table.weight"), didx, h, b, D, st);
     } else {
         const long per = (long)T * g.caption_dim; const size_t ib = text_dtype == CAR_DT_BF16 ? 2 : 4;
@@ -1520,6 +1522,12 @@ extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
         c->stats.decode_algo_bytes = (int64_t)(c->st_wbytes * c->st_nsteps + kvb);
     }
     *out = c->stats;
+    if (c->dev_flags.p) {        // sticky device-side error flags (this entry synchronises anyway)
+        int f[2] = {0, 0};
+        (void)hipStreamSynchronize(c->stream);
+        if (hipMemcpy(f, c->dev_flags.p, 8, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+        if (f[0]) { (void)hipMemset(c->dev_flags.p, 0, 64); FAIL(c, "car_generate_c2i: a class label outside [0, %d] was passed (clamped to the null class on the device)", c->cfg.num_classes); }
+    }
     return 0;
 }
 
@@ -1686,15 +1694,21 @@ extern "C" int car_canny(car_ctx* c, const uint8_t* img_hwc, int32_t B, int32_t 
     hipStream_t caller = (hipStream_t)stream_, st = c->stream;
     const long HW = (long)H * W;
     const size_t map_bytes = ((size_t)B * HW + 3) & ~(size_t)3;
-    NEED(c, c->canny_map, map_bytes + 16);
-    unsigned char* map = (unsigned char*)c->canny_map.p; int* changed = (int*)(map + map_bytes);
+    // hysteresis: tile-local fixed points swept to a global one.  The sweeps are enqueued in batches of kSweeps; sweep i looks at the "changed" flag
+    // of sweep i-1 and exits at once when the fixed point was already reached, and the host looks at the LAST flag of a batch only: one wait per
+    // call for any ordinary picture (a weak-edge chain has to cross tile borders more than kSweeps times to need a second batch), instead of
+    // one host round trip per sweep.
+    constexpr int kSweeps = 24;
+    NEED(c, c->canny_map, map_bytes + 4 * (kSweeps + 1));
+    unsigned char* map = (unsigned char*)c->canny_map.p; int* flags = (int*)(map + map_bytes);
     fence_in(c, caller);
     car_launch_canny_grad_nms(img_hwc, map, B, H, W, (int)std::floor(low_threshold), (int)std::floor(high_threshold), st);
-    for (int it = 0; it < 100000; ++it) {
+    for (int batch = 0; batch < 100000; ++batch) {
         int h = 0;
-        HIPCHK(c, hipMemsetAsync(changed, 0, 4, st));
-        car_launch_canny_hyst(map, B, H, W, changed, st);
-        HIPCHK(c, hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemsetAsync(flags, 0, 4 * (kSweeps + 1), st));
+        HIPCHK(c, hipMemsetAsync(flags, 1, 1, st));                     // flags[0] = 1 (little-endian byte): the first sweep always runs
+        for (int i = 1; i <= kSweeps; ++i) car_launch_canny_hyst(map, B, H, W, flags + i - 1, flags + i, st);
+        HIPCHK(c, hipMemcpyAsync(&h, flags + kSweeps, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         if (!h) break;
     }

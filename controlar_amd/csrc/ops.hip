@@ -58,6 +58,19 @@ __global__ void gather_rows_kernel(const void* table, const int* idx, void* out,
     const long stride = (long)gridDim.x * blockDim.x, n = rows * D;
     for (; i < n; i += stride) { const long r = i / D; const int d = (int)(i - r * D); ((T*)out)[i] = ((const T*)table)[(long)idx[r] * D + d]; }
 }
+// c2i prefix: table row of every decode row = its image's class label, or the null class `num_classes` for the unconditional CFG half
+// (generate.py:141, gpt.py:89-96).  Out-of-range labels: clamped to the null class + sticky error flag (reported by car_get_stats).
+__global__ void label_index_kernel(const int64_t* labels, const int* row_img, const int* row_unc, int num_classes, int* idx, int* err_flag, int b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b) return;
+    int64_t l = row_unc[i] ? (int64_t)num_classes : labels[row_img[i]];
+    if (l < 0 || l > num_classes) { *err_flag = 1; l = num_classes; }
+    idx[i] = (int)l;
+}
+extern "C" void car_launch_label_index(const int64_t* labels, const int* row_img, const int* row_unc, int num_classes, int* idx, int* err_flag, int b, hipStream_t st) {
+    hipLaunchKernelGGL(label_index_kernel, dim3((b + 255) / 256), dim3(256), 0, st, labels, row_img, row_unc, num_classes, idx, err_flag, b);
+}
+
 extern "C" void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st) {
     long n = rows * D; int g = (int)((n + 255) / 256); if (g > 2048) g = 2048;
     LAUNCH_T(mode, gather_rows_kernel, dim3(g), dim3(256), st, table, idx, out, rows, D);

@@ -127,6 +127,11 @@ class Engine:
                  temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, sample_logits: bool = False, seed: int = 0,
                  forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
         c2i = self.cfg.gpt.model_type == "c2i"
+        if c2i and cond.device.type == "cpu" and cond.numel():
+            # labels that are still on the host are checked for free; device-resident labels are checked on the device (sticky flag, stats())
+            lo, hi = int(cond.min()), int(cond.max())
+            if lo < 0 or hi > self.cfg.gpt.num_classes:
+                raise RuntimeError(f"car_generate_c2i: class label out of range [0,{self.cfg.gpt.num_classes}] (got {lo}..{hi})")
         cond = cond.to(self.device)
         if c2i:
             cond = cond.to(torch.int64).contiguous().view(-1)          # class labels [B]

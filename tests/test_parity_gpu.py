@@ -122,6 +122,28 @@ def test_generate_is_deterministic_and_repeatable():
     eng.close()
 
 
+def test_exact_mode_is_batch_invariant():
+    """Exact mode: a sequence decodes to the same BITS alone and as a row of a larger batch (logits included) — every exact-mode kernel sums one
+    fixed-order fp32 chain per output and the split-KV attention always folds 16 partials.  (bench.py --precision fp32 found the one
+    batch-dependent choice: at 192 images row 0 left the reference's tokens at token 488 while a batch of 1 reproduced all 1024.)"""
+    cs = load_case("tiny_depth_cfg4")
+    eng = _engine(cs, "fp32")
+    B = cs["B"]
+    reps = 9                                            # 2 x 9 x B rows: another tile count and, before the fix, another split count
+    eng.encode_control(cs["img"].cuda())
+    t1, l1 = eng.generate(cs["emb"].cuda(), cs["n_new"], _mask(cs), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"], return_logits=True)
+    t1, l1 = t1.cpu(), l1.cpu()
+    assert np.array_equal(t1.numpy(), cs["gold"]["tokens"])
+    img, emb, mask = cs["img"].repeat(reps, 1, 1, 1), cs["emb"].repeat(reps, 1, 1), cs["mask"].repeat(reps, 1)
+    eng.encode_control(img.cuda())
+    t2, l2 = eng.generate(emb.cuda(), cs["n_new"], mask.cuda(), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"], return_logits=True)
+    t2, l2 = t2.cpu(), l2.cpu()
+    for r in range(reps):
+        assert torch.equal(t2[r * B:(r + 1) * B], t1), r
+        assert torch.equal(l2[r * B:(r + 1) * B], l1), r
+    eng.close()
+
+
 def test_error_paths_raise():
     cs = load_case("tiny_canny_cfg1")
     from controlar_amd.engine import Engine
@@ -291,6 +313,35 @@ def test_c2i_class_conditional(name, mk):
     assert d.max() < 0.8 and d.mean() < 0.08, (d.max(), d.mean())
     agree = toks.cpu().numpy() == gold["tokens"]
     assert agree[gold["margin"] > 0.5].all() and agree.mean() > 0.9
+    eng.close()
+
+
+def test_c2i_label_errors_without_host_round_trip():
+    """car_generate_c2i builds the label -> table-row map on the device (no stream synchronise, SURVEY §8b "no hidden sync"): host labels are range-checked
+    for free by the shim; device labels are checked by the kernel — clamped to the null class, reported by the next stats() — and the
+    result for VALID labels is unchanged (bit-identical to the host-validated path, including under CFG where the uncond rows take the null class)."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    cfg = C.tiny_c2i(64)
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    B = 3
+    x = synth.canny_like_control(B, 128, 128)
+    labels = torch.tensor([1, cfg.gpt.num_classes - 1, 0], dtype=torch.int64)
+    eng = Engine(cfg, "fp32"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(x.cuda())
+    a = eng.generate(labels, 8, None, cfg_scale=1.0).cpu()               # host labels (validated by the shim)
+    b = eng.generate(labels.cuda(), 8, None, cfg_scale=1.0).cpu()        # device labels (validated on the device)
+    assert torch.equal(a, b)
+    eng.stats()                                                          # no flag raised
+    with pytest.raises(RuntimeError, match="out of range"):
+        eng.generate(torch.tensor([1, cfg.gpt.num_classes + 3, 0]), 8, None)
+    bad = torch.tensor([1, cfg.gpt.num_classes + 3, 0], dtype=torch.int64).cuda()
+    t = eng.generate(bad, 8, None, cfg_scale=1.0).cpu()                  # enqueued without a host round trip: the error surfaces at the next sync point
+    with pytest.raises(RuntimeError, match="class label outside"):
+        eng.stats()
+    null = eng.generate(torch.tensor([1, cfg.gpt.num_classes, 0]).cuda(), 8, None, cfg_scale=1.0).cpu()
+    assert torch.equal(t, null)                                          # the offending row was decoded with the null class
+    eng.stats()                                                          # the flag is sticky once, then cleared
     eng.close()
 
 
