@@ -83,12 +83,24 @@ class Model:
         if name == "No preprocess":
             return image
         if self.preprocessor is None and name == "Canny":
-            # built-in: cv2.Canny on the GPU (car_canny, condition/canny.py:6-14) at the photo's own resolution; the caller resizes the map
-            # to 512x512 exactly as demo/model.py:127 does.  (The reference's external Preprocessor is not part of its repository.)
+            # built-in: cv2.Canny on the GPU (car_canny, condition/canny.py:6-14).  The reference's external Preprocessor (demo/model.py:15,32 — not part
+            # of its repository) resizes the photo to `detect_resolution` BEFORE detecting edges, by the rule of condition/utils.py:28-38
+            # (shorter side -> detect_resolution, both sides rounded to multiples of 64, Lanczos when enlarging / area when shrinking); the same
+            # rule is applied here with PIL's filters (cv2 is not available: LANCZOS / BOX are its counterparts, not bit-equal to cv2.resize).
+            # The caller then resizes the edge map to 512x512 exactly as demo/model.py:127 does.
+            from PIL import Image
             from .condition import CannyDetector
             if getattr(self, "_canny", None) is None:
                 self._canny = CannyDetector(self.device)
-            return self._canny(np.array(image.convert("RGB")), kw.get("low_threshold", 100), kw.get("high_threshold", 200))
+            img = image.convert("RGB")
+            res = kw.get("detect_resolution")
+            if res:
+                W0, H0 = img.size
+                k = float(res) / min(H0, W0)
+                H1, W1 = int(np.round(H0 * k / 64.0)) * 64, int(np.round(W0 * k / 64.0)) * 64
+                if (W1, H1) != (W0, H0) and H1 > 0 and W1 > 0:
+                    img = img.resize((W1, H1), Image.LANCZOS if k > 1 else Image.BOX)
+            return self._canny(np.array(img), kw.get("low_threshold", 100), kw.get("high_threshold", 200))
         if self.preprocessor is None:
             raise RuntimeError(f"Model: preprocessor '{name}' needs the preprocessor callable (the reference's external Preprocessor, demo/model.py:15,32); "
                                "'No preprocess' takes the image as the control map")

@@ -179,12 +179,30 @@ class VQModel:
         return self._engine
 
     def decode_code(self, code_b, shape=None, channel_first=True):
-        """vq_model.py:53-56: code_b [B, h*w] (or flat), shape [B, C, h, w] -> fp32 [B,3,16h,16w]."""
-        if shape is None or not channel_first:
-            raise NotImplementedError("decode_code needs shape=[B,C,h,w], channel_first=True (the only form on the path)")
+        """vq_model.py:53-56: code_b [B, h*w] (or flat), shape [B, C, h, w] -> fp32 [B,3,16h,16w].
+        The other two argument forms fail in the reference as well, and fail the same way here:
+          * shape=None      -> get_codebook_entry returns a 2-D [N, C] tensor (vq_model.py:262-277) and post_quant_conv rejects it;
+          * channel_first=False, shape=(B, h, w, C) -> the [B, h, w, C] tensor reaches the NCHW convolution with h "channels": a channel-count
+            error unless h happens to equal the codebook dimension (then the reference decodes a transposed latent, which no caller on the path does)."""
+        C = self.vq.codebook_embed_dim
+        if shape is None:
+            dims = [int(d) for d in code_b.shape] + [C]
+            if len(dims) == 2:
+                raise RuntimeError(f"Expected 3D (unbatched) or 4D (batched) input to conv2d, but got input of size: {dims} "
+                                   "(decode_code(shape=None) hands the raw codebook gather to post_quant_conv, vq_model.py:48-56,262-277)")
+            if len(dims) == 3 and dims[0] != C:      # [B, N, C] is taken for ONE unbatched image with B channels
+                raise RuntimeError(f"Given groups=1, weight of size [{self.vq.z_channels}, {C}, 1, 1], expected input[1, {dims[0]}, {dims[1]}, {dims[2]}] to have {C} channels, "
+                                   f"but got {dims[0]} channels instead (decode_code(shape=None), vq_model.py:48-56,262-277)")
+            raise NotImplementedError("decode_code(shape=None) only 'works' in the reference when the batch size equals the codebook dimension (it then decodes "
+                                      "the batch as one unbatched latent); not on the path")
+        if not channel_first:
+            B, h, w, c_last = shape
+            if h != C:
+                raise RuntimeError(f"Given groups=1, weight of size [{self.vq.z_channels}, {C}, 1, 1], expected input[{B}, {h}, {w}, {c_last}] to have {C} channels, "
+                                   f"but got {h} channels instead (decode_code(channel_first=False) feeds a [B,h,w,C] tensor to an NCHW convolution, vq_model.py:271-276)")
+            raise NotImplementedError("decode_code(channel_first=False) with h == codebook_embed_dim decodes a transposed latent in the reference; not on the path")
         B, _, h, w = shape
         return self.engine.vq_decode(code_b.reshape(B, h * w), h, w)
-
 
     def encode_indices(self, x):
         """min_encoding_indices of VQModel.encode(x) (vq_model.py:41-46 -> info[2]) as int32 [B, h*w]."""

@@ -86,6 +86,41 @@ def test_dropin_modules_import_and_factories_build_without_gpu():
     assert hasattr(vq, "decode_code") and hasattr(vq, "encode_indices") and callable(G.generate)
 
 
+def test_decode_code_argument_forms_fail_as_in_the_reference():
+    """VQModel.decode_code(shape=None) and (channel_first=False) are not usable in the reference either (vq_model.py:53-56,262-277: a 2-D gather, resp.
+    a [B,h,w,C] tensor, reaches the NCHW post_quant_conv): the drop-in raises the same exception type with the same reason; when the reference
+    tree is present (build container) its own behaviour is checked beside it."""
+    import sys
+    import torch
+    from controlar_amd import models as M
+    vq = M.VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8)
+    code = torch.zeros(2, 16, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="conv2d"):
+        vq.decode_code(code.reshape(-1))                               # shape=None, flat codes: a 2-D gather
+    with pytest.raises(RuntimeError, match="channels"):
+        vq.decode_code(code)                                           # shape=None, [B, N] codes: [B, N, C] taken for one unbatched image
+    with pytest.raises(RuntimeError, match="channels"):
+        vq.decode_code(code, (2, 4, 4, 8), channel_first=False)        # [B, h, w, C] with h != C
+    ref_root = "/root/reference"
+    if os.path.isdir(ref_root):
+        sys.path.insert(0, ref_root)
+        try:
+            from tokenizer.tokenizer_image.vq_model import VQ_models as RefVQ
+        except Exception:
+            return
+        finally:
+            sys.path.remove(ref_root)
+        ref = RefVQ["VQ-16"](codebook_size=64, codebook_embed_dim=8).eval()
+        with torch.no_grad():
+            with pytest.raises(RuntimeError, match="conv2d"):
+                ref.decode_code(code.reshape(-1))
+            with pytest.raises(RuntimeError, match="channels"):
+                ref.decode_code(code)
+            with pytest.raises(RuntimeError, match="channels"):
+                ref.decode_code(code, (2, 4, 4, 8), channel_first=False)
+            assert tuple(ref.decode_code(code, (2, 8, 4, 4)).shape) == (2, 3, 64, 64)     # the one form the path uses
+
+
 def test_header_is_valid_c99_and_example_compiles():
     """include/controlar_hip.h must stay a plain C header (extern "C" boundary): gcc -std=c99 syntax-checks the C example."""
     import shutil
