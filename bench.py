@@ -231,6 +231,10 @@ def main():
     t_bcast = time.perf_counter() - t_bc0                     # host synthesis of the shards + H2D + the point-to-point sends
     shard_bytes = int(sum(__import__("controlar_amd.dist", fromlist=["packed_layout"]).packed_layout(args.batch, Hh, Ww, T, cap)))
     img, emb, mask = img.contiguous(), emb.contiguous(), mask.contiguous()
+    if args.precision == "fp32":
+        # exact mode takes the caption features in fp32 (the packed transport buffer carries bf16): redraw this rank's rows unrounded,
+        # so that row 0 is bit for bit the input of the committed XL golden (the control maps are {-1,+1}: exact in either type)
+        emb = torch.stack([synth.text_embeddings(1, T, cap, seed=1234 + rank + world * j)[0][0] for j in range(args.batch)]).to(dev)
     # self-check rows: with >= 4 images the first image of the second half (the second decode chain when the batch is cut in
     # two, engine.hip generate_impl) repeats local image 0 — identical inputs must come out as identical tokens and pixels
     twin = args.batch // 2 if args.batch >= 4 else -1

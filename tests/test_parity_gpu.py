@@ -124,8 +124,9 @@ def test_generate_is_deterministic_and_repeatable():
 
 def test_exact_mode_is_batch_invariant():
     """Exact mode: a sequence decodes to the same BITS alone and as a row of a larger batch (logits included) — every exact-mode kernel sums one
-    fixed-order fp32 chain per output and the split-KV attention always folds 16 partials.  (bench.py --precision fp32 found the one
-    batch-dependent choice: at 192 images row 0 left the reference's tokens at token 488 while a batch of 1 reproduced all 1024.)"""
+    fixed-order fp32 chain per output and the split-KV attention always folds 16 partials (a batch-dependent split count would fold a row's
+    softmax partial sums in another order).  At XL the same property is checked by `bench.py --precision fp32`: row 0 of a batch of 192 must
+    reproduce all 1024 tokens of the B = 1 golden."""
     cs = load_case("tiny_depth_cfg4")
     eng = _engine(cs, "fp32")
     B = cs["B"]
