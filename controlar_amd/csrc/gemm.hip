@@ -499,6 +499,133 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(GemmP p) {
     }
 }
 
+// conv3_halo64_kernel (round 3): the same tile (16x16 output pixels x 128 output channels, 8 waves, the same accumulation order per output:
+// 64-channel groups ascending, taps ascending inside a group — the OLD kernel walks taps inside 128-channel groups, so results agree to fp32
+// summation order, not bit for bit) with HALF the LDS: the halo is staged in 64-channel groups ([HP][64] bf16 = 41 KB instead of 83 KB) and the weight
+// ring has two stages (one tap of 64 channels = 16 KiB in flight).  75 KB per workgroup puts TWO workgroups on a CU: conv3_halo_kernel's single
+// 131-KB workgroup leaves the matrix cores idle during its halo load, at every weight-stage wait and through its epilogue (27 us per tile against
+// 8 us of MFMA work); with two, one workgroup's waits sit under the other's MFMAs.
+// LDS: halo pixel h = 8 chunks of 16 B, chunk c at slot c ^ (h & 7); weight stage [128 n][64 k], chunk c of row r at slot c ^ (r & 7).
+// Requirements: Cin % 64 == 0, Ho % 16 == 0, Wo % 16 == 0.
+#define CH64_HALO_PIX 328                                   // 18 x 18 = 324 rounded up to whole 8-pixel DMA pieces
+template <int UPS>
+__global__ __launch_bounds__(512, 4) void conv3_halo64_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem4[];
+    constexpr int HD = (16 >> UPS) + 2, HP = HD * HD;
+    bf16_t* halo = smem4;                                   // [CH64_HALO_PIX][64]
+    bf16_t* wst = smem4 + CH64_HALO_PIX * 64;               // 2 x [128][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * BN, tile = blockIdx.y;
+    const int tw = p.Wo >> 4, th = p.Ho >> 4;
+    const int b = tile / (tw * th), t2 = tile - b * (tw * th), ty = t2 / tw, tx = t2 - ty * tw;
+    const int Hin = p.Ho >> UPS, Win = p.Wo >> UPS;
+    const int hy0 = ((16 * ty - 1) >> UPS), hx0 = ((16 * tx - 1) >> UPS);      // arithmetic shift: -1 >> 1 == -1
+    const bf16_t* A = (const bf16_t*)p.A + (long)b * Hin * Win * p.Cin;
+    const bf16_t* W = (const bf16_t*)p.W;
+    const bf16_t* zero = (const bf16_t*)p.zero;
+    const int fr = lane & 15, fq = lane >> 4;
+    // weight loader: wave w, pass i covers rows i*64 + w*8 .. +8 of the 128 n rows
+    const int lr = lane >> 3, gchunk = ((lane & 7) ^ lr) * 8;
+    const bf16_t* wrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int r = i * 64 + wave * 8 + lr; wrow[i] = (n0 + r) < p.N ? W + (long)(n0 + r) * p.ldw + gchunk : nullptr; }
+    auto issue_w = [&](int buf, int kglob) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* src = wrow[i] ? wrow[i] + kglob : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(wst + buf * (BN * G2_BK) + (i * 64 + wave * 8) * G2_BK), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // halo pixel index of output pixel (row 4*wm + i, column fr) under tap (dy, dx), hoisted per tap
+    const int ngrp = p.Cin >> 6;
+    for (int cg = 0; cg < ngrp; ++cg) {
+        __syncthreads();                                   // everyone is done with the previous group's halo and weight stages
+        // ---- halo of this 64-channel group: one wave instruction = 8 pixels x 128 B
+        for (int q = wave; q * 8 < HP; q += 8) {
+            const int pix = q * 8 + (lane >> 3), slot = lane & 7;
+            const int hy = pix / HD, hx = pix - hy * HD, iy = hy0 + hy, ix = hx0 + hx;
+            const bf16_t* src = zero;
+            if (pix < HP && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) src = A + ((long)iy * Win + ix) * p.Cin + cg * 64 + ((slot ^ (pix & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(halo + q * 8 * 64), 16, 0, 0);
+        }
+        issue_w(0, cg * 64);                               // tap 0 of this group: global k = tap * Cin + cg * 64
+        int buf = 0;
+        for (int tap = 0; tap < 9; ++tap) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage `tap` (and, at tap 0, of the halo) have landed
+            __builtin_amdgcn_s_barrier();                         // ... so have everyone's; and everyone is done reading the other buffer
+            if (tap + 1 < 9) issue_w(buf ^ 1, (tap + 1) * p.Cin + cg * 64);
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const bf16_t* ws = wst + buf * (BN * G2_BK);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 a[4], bb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int h = (((16 * ty + wm * 4 + i + dy) >> UPS) - hy0) * HD + (((16 * tx + fr + dx) >> UPS) - hx0);
+                    a[i] = *(const bf16x8*)(halo + h * 64 + (((kk * 4 + fq) ^ (h & 7)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int r = wn * 64 + j * 16 + fr; bb[j] = *(const bf16x8*)(ws + r * G2_BK + (((kk * 4 + fq) ^ (r & 7)) << 3)); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+    }
+    __syncthreads();
+    // ---- epilogue (as conv3_halo_kernel): out = rnd(rnd(acc + bias) + R), 16-byte loads/stores: lane = (pixel rr of the patch row, 8 consecutive channels)
+    const bf16_t* bias = (const bf16_t*)p.bias; const bf16_t* R = (const bf16_t*)p.R;
+    float* strip = (float*)smem4 + wave * (16 * 68);
+    const int ec = (lane & 7) * 8, en = n0 + wn * 64 + ec;
+    float bv[8];
+    {
+        const uint4 u = bias ? *(const uint4*)(bias + en) : make_uint4(0, 0, 0, 0);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bv[2 * e] = __uint_as_float(w[e] << 16); bv[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 q = acc[i][j];
+            float* d = strip + ((lane >> 4) * 4) * 68 + j * 16 + fr;
+            d[0] = q[0]; d[68] = q[1]; d[136] = q[2]; d[204] = q[3];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int oy = 16 * ty + wm * 4 + i;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int rr = pass * 8 + (lane >> 3);
+            const long mr = ((long)b * p.Ho + oy) * p.Wo + 16 * tx + rr;
+            const float4 s0 = *(const float4*)(strip + rr * 68 + ec), s1 = *(const float4*)(strip + rr * 68 + ec + 4);
+            float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e] + bv[e]));
+            if (R) {
+                const uint4 u = *(const uint4*)(R + mr * p.ldr + en);
+                const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] = v[2 * e] + __uint_as_float(w[e] << 16); v[2 * e + 1] = v[2 * e + 1] + __uint_as_float(w[e] & 0xffff0000u); }
+            }
+            uint4 o;
+            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+            *(uint4*)((bf16_t*)p.C + mr * p.ldc + en) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // =========================================================================== fp32 exact
 template <int AMODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
@@ -576,6 +703,20 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
             p.K == 9 * p.Cin && p.ldw % 8 == 0 && (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.W % 16 == 0 && !p.swiglu && !p.out_f32 && p.act == ACT_NONE &&
             p.nb0 * p.nb1 == 1 && p.alpha == 1.0f && p.N % 128 == 0 && !p.scale && p.bias_mode != BIAS_M && p.ldc % 8 == 0 && (!p.R || p.ldr % 8 == 0) &&
             !getenv("CAR_GEMM_V1") && !getenv("CAR_NO_HALO")) {
+            p.zero = zero_page[dev];
+            const dim3 g3((p.N + BN - 1) / BN, (unsigned)((long)p.M / 256));
+            if (!getenv("CAR_CONV_HALO128")) {          // default: the 75-KB form, two workgroups per CU (A/B switch: CAR_CONV_HALO128=1 -> the 131-KB kernel)
+                static bool attr4 = false;
+                const size_t sh4 = (size_t)(CH64_HALO_PIX * 64 + 2 * BN * G2_BK) * 2;
+                if (!attr4) {
+                    (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+                    (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+                    attr4 = true;
+                }
+                if (p.ups == 0) hipLaunchKernelGGL(conv3_halo64_kernel<0>, g3, dim3(512), sh4, st, p);
+                else hipLaunchKernelGGL(conv3_halo64_kernel<1>, g3, dim3(512), sh4, st, p);
+                return;
+            }
             static bool attr3 = false;
             const size_t sh3 = (size_t)(CH_HALO_MAX * 128 + 3 * BN * G2_BK) * 2;
             if (!attr3) {
@@ -583,8 +724,6 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
                 (void)hipFuncSetAttribute((const void*)conv3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3);
                 attr3 = true;
             }
-            p.zero = zero_page[dev];
-            const dim3 g3((p.N + BN - 1) / BN, (unsigned)((long)p.M / 256));
             if (p.ups == 0) hipLaunchKernelGGL(conv3_halo_kernel<0>, g3, dim3(512), sh3, st, p);
             else hipLaunchKernelGGL(conv3_halo_kernel<1>, g3, dim3(512), sh3, st, p);
             return;
