@@ -94,4 +94,7 @@ struct GemmP {
     int patch;            // AMODE_CONV3, bf16 kernels: GEMM rows enumerate the output in 16x16 spatial patches (Ho, Wo multiples of 16) so that a
                           // tile's nine taps re-read an 18x18 halo that stays in L2, instead of three full image rows
     const void* zero;     // >= 16 zero bytes in device memory: source of padded / out-of-range chunks of the LDS-DMA loader (set by car_launch_gemm)
+    float* gn_part;       // conv3_halo64_kernel only (car_conv3_halo64_ok): if set, the epilogue also writes the GroupNorm stage-1 partials of its OUTPUT
+                          // tensor — per (image, 16x16 tile, channel) sum and sum of squares of the stored bf16 values, layout [B][Ho*Wo/256][2][N] =
+                          // what gn_partial_vec_kernel writes with one 256-pixel chunk per tile — so the next GroupNorm skips its read-only pass
 };

@@ -84,6 +84,7 @@ struct FlashP {
 };
 int car_launch_flash64(const FlashP* p, int B, hipStream_t st);
 void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
+int car_conv3_halo64_ok(int mode, const GemmP* p);
 void car_launch_convert(int mode, const void* src, int src_dtype, void* dst, long n, hipStream_t st);
 void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg, hipStream_t st);
 void car_launch_layernorm(int mode, const void* x, const void* w, const void* b, void* y, long rows, int D, float eps, hipStream_t st);
@@ -95,6 +96,7 @@ void car_launch_patchify(int mode, const void* img, int img_dtype, void* out, in
 void car_launch_vit_assemble(int mode, const void* tok, const void* cls, const void* pos, void* h, int B, int n, int D, hipStream_t st);
 void car_launch_groupnorm(int mode, const void* x, const void* gamma, const void* beta, void* y, float* part, float* stats,
                           int B, int HW, int C, int G, float eps, int swish, hipStream_t st);
+void car_launch_groupnorm_ex(int mode, const void* x, const void* gamma, const void* beta, void* y, float* part, float* stats, int B, int HW, int C, int G, float eps, int swish, int have_part, hipStream_t st);
 void car_launch_vq_lookup(int mode, const int* tok, const float* cb, const float* wpq, const float* bpq, void* z, long npix, int cd, int zc, int ncode, hipStream_t st);
 void car_launch_conv_in3(int mode, const float* img, const void* w, const void* b, void* out, int B, int H, int W, int Co, hipStream_t st);
 void car_launch_vq_argmin(int mode, const void* z, const float* cb, int* tok, long npix, int cd, int ncode, hipStream_t st);
@@ -1722,19 +1724,28 @@ extern "C" int car_canny(car_ctx* c, const uint8_t* img_hwc, int32_t B, int32_t 
 // ------------------------------------------------------------------------------------- VQ building blocks (shared by decode and encode)
 struct VqOps {
     car_ctx* c; int mode; size_t e; hipStream_t st;
+    // GroupNorm stage 1 for free: a 3x3 conv that takes conv3_halo64_kernel also writes the per-tile sum / sum-of-squares partials of its OUTPUT from the
+    // epilogue (GemmP::gn_part -> ws[8], the layout of gn_partial_vec_kernel), and a GroupNorm whose input is that very tensor skips its read-only pass.
+    // `part_of` = the tensor whose partials ws[8] currently holds (null: none); every other writer of a tensor clears it.
+    mutable const void* part_of = nullptr;
     void conv3(const void* x, void* y, const std::string& name, int nb, int Ho, int Wo, int Cin, int Cout, int ups, const void* R, int amode = AMODE_CONV3) const {
         GemmP q = gp(x, 0, Wp(c, name + ".weight"), 9 * (long)Cin, y, Cout, nb * Ho * Wo, Cout, 9 * Cin);
         q.bias = Wp(c, name + ".bias"); q.bias_mode = BIAS_N; q.Ho = Ho; q.Wo = Wo; q.Cin = Cin; q.ups = ups; q.R = R; q.ldr = Cout;
         q.patch = 1;        // 16x16 spatial patch order of the GEMM rows where the launcher can use it (bf16, Ho and Wo multiples of 16)
+        part_of = nullptr;
+        if (amode == AMODE_CONV3 && car_conv3_halo64_ok(mode, &q) && Cout <= 512) { q.gn_part = (float*)c->ws[8].p; part_of = y; }
         car_launch_gemm(mode, amode, &q, st);
     }
     void conv1(const void* x, void* y, const std::string& name, int M, int Cin, int Cout, const void* R) const {
         GemmP q = gp(x, Cin, Wp(c, name + ".weight"), Cin, y, Cout, M, Cout, Cin);
         q.bias = Wp(c, name + ".bias"); q.bias_mode = BIAS_N; q.R = R; q.ldr = Cout;
+        part_of = nullptr;
         car_launch_gemm(mode, AMODE_PLAIN, &q, st);
     }
     void gn(const void* x, void* y, const std::string& name, int nb, int HW, int C, int swish) const {
-        car_launch_groupnorm(mode, x, Wp(c, name + ".weight"), Wp(c, name + ".bias"), y, (float*)c->ws[8].p, (float*)c->ws[9].p, nb, HW, C, 32, c->cfg.gn_eps, swish, st);
+        const int have = (part_of != nullptr && part_of == x) ? 1 : 0;
+        car_launch_groupnorm_ex(mode, x, Wp(c, name + ".weight"), Wp(c, name + ".bias"), y, (float*)c->ws[8].p, (float*)c->ws[9].p, nb, HW, C, 32, c->cfg.gn_eps, swish, have, st);
+        part_of = nullptr;
     }
     // kinds: 0 ResnetBlock (vq_model.py:300-315), 1 AttnBlock (:328-352, single head over HW positions),
     //        2 Upsample (nearest x2 folded into the conv gather, :375-379), 3 Downsample (pad (0,1,0,1) + conv stride 2, :382-396)

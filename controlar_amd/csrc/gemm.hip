@@ -7,6 +7,8 @@
 //     with zero padding and an optional fused nearest x2 upsample (vq_model.py:375-379).
 // The epilogue reproduces the reference's rounding points (one rounding per torch op).
 #include "car_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 template <typename T>
 __device__ __forceinline__ float epi_value(const GemmP& p, const T* bias, const T* scale, const T* R, long zR, int m, long mrow, int n, float v) {
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(GemmP p) {
 // LDS: halo pixel h = 8 chunks of 16 B, chunk c at slot c ^ (h & 7); weight stage [128 n][64 k], chunk c of row r at slot c ^ (r & 7).
 // Requirements: Cin % 64 == 0, Ho % 16 == 0, Wo % 16 == 0.
 #define CH64_HALO_PIX 328                                   // 18 x 18 = 324 rounded up to whole 8-pixel DMA pieces
-template <int UPS>
+template <int UPS, int GNP>
 __global__ __launch_bounds__(512, 4) void conv3_halo64_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem4[];
     constexpr int HD = (16 >> UPS) + 2, HP = HD * HD;
@@ -593,6 +595,9 @@ __global__ __launch_bounds__(512, 4) void conv3_halo64_kernel(GemmP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bv[2 * e] = __uint_as_float(w[e] << 16); bv[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
     }
+    float gs[8], gq[8];                         // GroupNorm stage-1 partials of this lane's 8 channels over its 8 pixels (p.gn_part)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -621,8 +626,36 @@ __global__ __launch_bounds__(512, 4) void conv3_halo64_kernel(GemmP p) {
             o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
             o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
             *(uint4*)((bf16_t*)p.C + mr * p.ldc + en) = o;
+            if (GNP) {                           // statistics of the values as STORED (bf16), as the separate pass would read them back
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float r_ = bf2f(f2bf(v[e])); gs[e] += r_; gq[e] += r_ * r_; }
+            }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (GNP) {
+        // fold in a fixed order: 8 lanes of a wave share a channel chunk (lane & 7) -> xor 8, 16, 32; then the 4 waves of a channel half through LDS
+        float* red = (float*)smem4 + 8 * (16 * 68);          // [8 waves][64 ch][2], behind the epilogue strips
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o_ = 8; o_ < 64; o_ <<= 1) { gs[e] += __shfl_xor(gs[e], o_, 64); gq[e] += __shfl_xor(gq[e], o_, 64); }
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[(wave * 64 + lane * 8 + e) * 2] = gs[e]; red[(wave * 64 + lane * 8 + e) * 2 + 1] = gq[e]; }
+        }
+        __syncthreads();
+        if (tid < 128) {                         // channel n0 + tid: waves (wm, wn) with wn = tid / 64, wm = 0..3 in order
+            const int wn2 = tid >> 6, cc = tid & 63;
+            float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) { const float* r2 = red + ((w4 * 2 + wn2) * 64 + cc) * 2; s_ += r2[0]; q_ += r2[1]; }
+            if (n0 + tid < p.N) {
+                float* o2 = p.gn_part + ((long)b * (tw * th) + t2) * 2 * p.N;
+                o2[n0 + tid] = s_; o2[p.N + n0 + tid] = q_;
+            }
+        }
     }
 }
 
@@ -686,6 +719,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 }
 
 // host launchers -------------------------------------------------------------------------
+// Will car_launch_gemm(mode, AMODE_CONV3, p) take conv3_halo64_kernel — the kernel whose epilogue can also write the GroupNorm stage-1 partials of its
+// output (GemmP::gn_part)?  engine.hip asks before it lets the next GroupNorm skip its read-only pass.
+extern "C" int car_conv3_halo64_ok(int mode, const GemmP* pp) {
+    const GemmP& p = *pp;
+    return mode == 1 && p.Cin % 128 == 0 && (p.Ho & 15) == 0 && (p.Wo & 15) == 0 && (p.ups == 0 || p.ups == 1) && p.K == 9 * p.Cin && p.ldw % 8 == 0 &&
+           (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.W % 16 == 0 && !p.swiglu && !p.out_f32 && p.act == ACT_NONE && (p.nb0 <= 1) && (p.nb1 <= 1) && p.alpha == 1.0f &&
+           p.N % 128 == 0 && !p.scale && p.bias_mode != BIAS_M && p.ldc % 8 == 0 && (!p.R || p.ldr % 8 == 0) &&
+           !getenv("CAR_GEMM_V1") && !getenv("CAR_NO_HALO") && !getenv("CAR_CONV_HALO128") && !getenv("CAR_GN_UNFUSED");
+}
 extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_t st) {
     GemmP p = *pp;
     if (p.nb0 <= 0) p.nb0 = 1;
@@ -705,16 +747,19 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
             !getenv("CAR_GEMM_V1") && !getenv("CAR_NO_HALO")) {
             p.zero = zero_page[dev];
             const dim3 g3((p.N + BN - 1) / BN, (unsigned)((long)p.M / 256));
+            if (p.gn_part && getenv("CAR_CONV_HALO128")) { fprintf(stderr, "car_launch_gemm: GemmP::gn_part needs conv3_halo64_kernel\n"); abort(); }
             if (!getenv("CAR_CONV_HALO128")) {          // default: the 75-KB form, two workgroups per CU (A/B switch: CAR_CONV_HALO128=1 -> the 131-KB kernel)
                 static bool attr4 = false;
                 const size_t sh4 = (size_t)(CH64_HALO_PIX * 64 + 2 * BN * G2_BK) * 2;
                 if (!attr4) {
-                    (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
-                    (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+                    (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+                    (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+                    (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
+                    (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
                     attr4 = true;
                 }
-                if (p.ups == 0) hipLaunchKernelGGL(conv3_halo64_kernel<0>, g3, dim3(512), sh4, st, p);
-                else hipLaunchKernelGGL(conv3_halo64_kernel<1>, g3, dim3(512), sh4, st, p);
+                if (p.ups == 0) { if (p.gn_part) hipLaunchKernelGGL((conv3_halo64_kernel<0, 1>), g3, dim3(512), sh4, st, p); else hipLaunchKernelGGL((conv3_halo64_kernel<0, 0>), g3, dim3(512), sh4, st, p); }
+                else { if (p.gn_part) hipLaunchKernelGGL((conv3_halo64_kernel<1, 1>), g3, dim3(512), sh4, st, p); else hipLaunchKernelGGL((conv3_halo64_kernel<1, 0>), g3, dim3(512), sh4, st, p); }
                 return;
             }
             static bool attr3 = false;
@@ -728,6 +773,7 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
             else hipLaunchKernelGGL(conv3_halo_kernel<1>, g3, dim3(512), sh3, st, p);
             return;
         }
+        if (p.gn_part) { fprintf(stderr, "car_launch_gemm: GemmP::gn_part set but the call does not take conv3_halo64_kernel (ask car_conv3_halo64_ok first)\n"); abort(); }
         const bool al16 = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && p.ldw % 8 == 0 && p.sW0 % 8 == 0 && p.sW1 % 8 == 0 && p.sA0 % 8 == 0 && p.sA1 % 8 == 0;
         const long tiles = (long)((p.N + BN - 1) / BN) * ((p.M + G2_BM - 1) / G2_BM) * p.nb0 * p.nb1;
         const bool ok2 = dev >= 0 && dev < 16 && p.K % G2_BK == 0 && p.K >= 512 && al16 && tiles >= 512 && !getenv("CAR_GEMM_V1") &&
@@ -752,6 +798,7 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
         else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_CONV3>, g, dim3(256), 0, st, p);
     } else {
+        if (p.gn_part) { fprintf(stderr, "car_launch_gemm: GemmP::gn_part is a bf16 conv3_halo64_kernel feature\n"); abort(); }
         p.patch = 0;                              // the exact-mode kernel enumerates pixels linearly
         dim3 g((p.N + 63) / 64, (p.M + 63) / 64, p.nb0 * p.nb1);
         if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_f32_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);

@@ -405,15 +405,19 @@ __global__ __launch_bounds__(256) void gn_partial_vec_kernel(const bf16_t* __res
     }
 }
 
-extern "C" void car_launch_groupnorm(int mode, const void* x, const void* gamma, const void* beta, void* y, float* part, float* stats,
-                                     int B, int HW, int C, int G, float eps, int swish, hipStream_t st) {
+// have_part != 0: `part` already holds the stage-1 partials of x (written by the producing conv's epilogue, GemmP::gn_part: one 256-pixel chunk per
+// 16x16 tile, the same [B][nchunk][2][C] layout): the read-only pass over x is skipped.
+extern "C" void car_launch_groupnorm_ex(int mode, const void* x, const void* gamma, const void* beta, void* y, float* part, float* stats,
+                                        int B, int HW, int C, int G, float eps, int swish, int have_part, hipStream_t st) {
     const int nchunk = (HW + GN_CHUNK - 1) / GN_CHUNK;
     const size_t shb = (2 * C + 512) * sizeof(float);
-    if (mode == 1 && C >= 8 && C <= 2048 && (C & (C - 1)) == 0)
+    if (have_part) { /* stage 1 done by the producer */ }
+    else if (mode == 1 && C >= 8 && C <= 2048 && (C & (C - 1)) == 0)
         hipLaunchKernelGGL(gn_partial_vec_kernel, dim3(nchunk, B), dim3(256), (size_t)256 * 16 * 4, st, (const bf16_t*)x, part, HW, C);
     else if (mode == 1) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
     else hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, st, part, stats, nchunk, C, G, HW, eps);
+    if (!y) return;              // statistics only
     if (mode == 1 && C >= 8 && C <= 2048 && (C & (C - 1)) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && !getenv("CAR_GN_SCALAR")) {
         const int nslot = 256 / (C >> 3); int ppb = nslot * 8; if (ppb > HW) ppb = HW;
         hipLaunchKernelGGL(gn_apply_vec_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)gamma, (const bf16_t*)beta,
@@ -422,6 +426,10 @@ extern "C" void car_launch_groupnorm(int mode, const void* x, const void* gamma,
     }
     long total = (long)B * HW * C; int g = (int)((total + 255) / 256); if (g > 8192) g = 8192;
     LAUNCH_T(mode, gn_apply_kernel, dim3(g), dim3(256), st, x, stats, gamma, beta, y, B, HW, C, G, swish);
+}
+extern "C" void car_launch_groupnorm(int mode, const void* x, const void* gamma, const void* beta, void* y, float* part, float* stats,
+                                     int B, int HW, int C, int G, float eps, int swish, hipStream_t st) {
+    car_launch_groupnorm_ex(mode, x, gamma, beta, y, part, stats, B, HW, C, G, eps, swish, 0, st);
 }
 
 // ------------------------------------------------------------------ codebook lookup + post_quant_conv (vq_model.py:262-277, :49)
