@@ -28,7 +28,7 @@ class CarConfig(C.Structure):
         ("vit_patch", C.c_int32), ("vit_pos_grid", C.c_int32), ("vit_ln_eps", C.c_float), ("resize_mode", C.c_int32),
         ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32), ("z_channels", C.c_int32), ("vq_ch", C.c_int32),
         ("vq_num_res_blocks", C.c_int32), ("vq_n_mult", C.c_int32), ("vq_ch_mult", C.c_int32 * 8), ("gn_eps", C.c_float),
-        ("vit_variant", C.c_int32), ("model_type", C.c_int32), ("num_classes", C.c_int32), ("stream_priority", C.c_int32), ("decode_weight_fp8", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("vit_variant", C.c_int32), ("model_type", C.c_int32), ("num_classes", C.c_int32), ("stream_priority", C.c_int32), ("decode_weight_fp8", C.c_int32), ("kv_cache_fp8", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 

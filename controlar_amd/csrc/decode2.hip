@@ -25,6 +25,11 @@
 //               (qv, ev) = w < 16 ? (w/4, w%4) : ((w-16)/4, 4 + (w-16)%4)
 // (the V position order inside a 32-block is the order in which the two 16x16 score tiles leave the accumulator, so P
 // needs no cross-lane movement between the two MFMAs).
+// e4m3 KV cache (car_config.kv_cache_fp8, opt-in; the reference has no such mode): one BYTE per element, unit scale, the same fragment geometry with two
+// MFMA operands per 16-byte lane slot (as the e4m3 weight image), streams of SA x 64 bytes per (sequence, head):
+//     K8 (p, d): (p/16)*1024 + (((d%32)/8)*16 + p%16)*16 + (d/32)*8 + d%8          (bytes 0-7: dims 0-31 operand, bytes 8-15: dims 32-63 operand)
+//     V8 (p, d): (p/32)*2048 + (d/32)*1024 + (qv*16 + d%16)*16 + ((d/16)%2)*8 + ev
+// dec_attn2 widens the bytes to bf16 in registers (exact: e4m3 is a subset of bf16) in front of the same bf16 MFMAs.
 #include "car_common.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -59,6 +64,7 @@ struct GemmDP {
     const float* rope;    // [n_pos][32][2]
     const int* pos;
     int H, SA, dim;
+    int kv8;              // EPI_QKV: K / V rows are stored as OCP e4m3 bytes (K8 / V8 layouts above) instead of bf16
     // NORM kernels (M <= 16): X = RMSNorm of the residual stream, computed in the prologue of every workgroup (K = model dim):
     //   v = gather ? emb[idx[m]] : h_in[m] ; (+ control token at *pos, gpt_t2i.py:466) ; workgroup 0 stores v to h_out if set ;
     //   x = rnd(rnd(v * rsqrt(mean v^2 + eps)) * w)     — the arithmetic of rmsnorm2_kernel, gpt_t2i.py:193-198
@@ -67,14 +73,13 @@ struct GemmDP {
 };
 
 // OCP e4m3fn bytes -> bf16 (exact: e4m3 is a subset of bf16).  lo/hi: 4 bytes each = 8 consecutive k of one row.
+// v_cvt_scalef32_pk_bf16_fp8 (gfx950): two bytes -> a packed bf16 pair in ONE instruction (scale 1.0); four per fragment where the
+// cvt_pk_f32_fp8 + shift/mask form needed sixteen — it matters in dec_attn2's e4m3-KV form, which widens every byte it streams.
 __device__ inline bf16x8 fp8x8_to_bf16x8_(unsigned lo, unsigned hi) {
-    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
-    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    const bf16x2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+    const bf16x2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
     u32x4 r;
-    r[0] = (__float_as_uint(a[0]) >> 16) | (__float_as_uint(a[1]) & 0xffff0000u);
-    r[1] = (__float_as_uint(b[0]) >> 16) | (__float_as_uint(b[1]) & 0xffff0000u);
-    r[2] = (__float_as_uint(c[0]) >> 16) | (__float_as_uint(c[1]) & 0xffff0000u);
-    r[3] = (__float_as_uint(d[0]) >> 16) | (__float_as_uint(d[1]) & 0xffff0000u);
+    r[0] = *(const unsigned*)&a; r[1] = *(const unsigned*)&b; r[2] = *(const unsigned*)&c; r[3] = *(const unsigned*)&d;
     return *(bf16x8*)&r;
 }
 
@@ -299,8 +304,14 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                     const long sb = ((long)m * p.H + hh) * p.SA * 64;
                     if (sec == 2) {
                         const int w = pos & 31, qv = w < 16 ? (w >> 2) : ((w - 16) >> 2), ev = w < 16 ? (w & 3) : (4 + ((w - 16) & 3));
-                        bf16_t* vb = p.vc + sb + ((long)(pos >> 5) * 4 + (d0 >> 4)) * 512 + ((qv * 16 + (d0 & 15)) << 3) + ev;
-                        vb[0] = f2bf(x0); vb[8] = f2bf(x1); vb[16] = f2bf(x2); vb[24] = f2bf(x3);
+                        if (p.kv8) {
+                            unsigned char* vb = (unsigned char*)p.vc + sb + (long)(pos >> 5) * 2048 + (d0 >> 5) * 1024 + ((qv * 16 + (d0 & 15)) << 4) + ((d0 >> 4) & 1) * 8 + ev;
+                            const int e01 = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false), e23 = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, 0, false);
+                            vb[0] = (unsigned char)(e01 & 0xff); vb[16] = (unsigned char)((e01 >> 8) & 0xff); vb[32] = (unsigned char)(e23 & 0xff); vb[48] = (unsigned char)((e23 >> 8) & 0xff);
+                        } else {
+                            bf16_t* vb = p.vc + sb + ((long)(pos >> 5) * 4 + (d0 >> 4)) * 512 + ((qv * 16 + (d0 & 15)) << 3) + ev;
+                            vb[0] = f2bf(x0); vb[8] = f2bf(x1); vb[16] = f2bf(x2); vb[24] = f2bf(x3);
+                        }
                     } else {
                         const float4 cs = *(const float4*)(p.rope + ((long)pos * 32 + (d0 >> 1)) * 2);   // (cos, sin) of pairs d0/2, d0/2+1
                         const float r0 = x0 * cs.x - x1 * cs.y, r1 = x1 * cs.x + x0 * cs.y;
@@ -311,6 +322,11 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                             o.x = pack_bf16x2(bf2f(f2bf(r0)) * 0.125f, bf2f(f2bf(r1)) * 0.125f);
                             o.y = pack_bf16x2(bf2f(f2bf(r2)) * 0.125f, bf2f(f2bf(r3)) * 0.125f);
                             *(uint2*)(p.qout + ((long)m * p.H + hh) * 64 + d0) = o;
+                        } else if (p.kv8) {       // rotated k: bf16 round (the Linear -> RoPE rounding points), then e4m3
+                            unsigned char* kb_ = (unsigned char*)p.kc + sb + (long)(pos >> 4) * 1024 + ((((d0 & 31) >> 3) * 16 + (pos & 15)) << 4) + (d0 >> 5) * 8 + (d0 & 7);
+                            int e = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(f2bf(r0)), bf2f(f2bf(r1)), 0, false);
+                            e = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(f2bf(r2)), bf2f(f2bf(r3)), e, true);
+                            *(unsigned*)kb_ = (unsigned)e;
                         } else {
                             uint2 o; o.x = pack_bf16x2(r0, r1); o.y = pack_bf16x2(r2, r3);
                             bf16_t* kb_ = p.kc + sb + ((long)(pos >> 4) * 2 + (d0 >> 5)) * 512 + ((((d0 & 31) >> 3) * 16 + (pos & 15)) << 3) + (d0 & 7);
@@ -399,12 +415,13 @@ struct Attn2P {
     bf16_t* out;                // nsplit == 1: attention output, XP-packed [ceil(b/16)][dim/32][64][8] if out_packed else [b][dim]
     float* part;                // nsplit > 1: [b][H][nsplit][66] (m, l, o[64])
     int H, SA, T, dim, nsplit, out_packed;
+    int kv8;                    // the caches hold e4m3 bytes (K8 / V8 layouts), widened to bf16 in registers
     int n_seq, pgrid;           // persistent form (nsplit == 1): n_seq > 0 sequences, a 1-D grid of pgrid workgroups walks the n_seq*H items
 };
 
 // NWAVE waves share one (sequence, head): wave w of split s takes 32-position blocks blk0 + s*NWAVE + w, stride nsplit*NWAVE.
 // PF = 1 keeps the next block's 8 KiB in flight in a second register set while the current one is consumed.
-template <int NWAVE, int PF>
+template <int NWAVE, int PF, int KV8>
 __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     __shared__ float red[NWAVE][66];
     const int split = blockIdx.z;
@@ -419,8 +436,8 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     for (int it = persist ? (int)blockIdx.x : 0; it < n_items; it += gridDim.x) {
     const int h = persist ? it % p.H : (int)blockIdx.x, b = persist ? it / p.H : (int)blockIdx.y;
     const long sbase = ((long)b * p.H + h) * p.SA * 64;
-    const u32x4* Kp = (const u32x4*)(p.kc + sbase) + lane;
-    const u32x4* Vp = (const u32x4*)(p.vc + sbase) + lane;
+    const u32x4* Kp = KV8 ? (const u32x4*)((const unsigned char*)p.kc + sbase) + lane : (const u32x4*)(p.kc + sbase) + lane;
+    const u32x4* Vp = KV8 ? (const u32x4*)((const unsigned char*)p.vc + sbase) + lane : (const u32x4*)(p.vc + sbase) + lane;
     const bf16_t* qp = p.q + ((long)b * p.H + h) * 64;
     const bf16x8 qf0 = *(const bf16x8*)(qp + q4 * 8), qf1 = *(const bf16x8*)(qp + 32 + q4 * 8);
     const unsigned char* mk = p.mask ? p.mask + (long)b * p.T : nullptr;
@@ -442,13 +459,27 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // KV8: a 32-position block is 2 + 2 KiB instead of 4 + 4: two 16-byte loads per lane for K and two for V (kr[0..1], vr[0..1]), each carrying the
+    // bytes of two MFMA operands
     auto load = [&](u32x4 (&kr)[4], u32x4 (&vr)[4], int blk) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) kr[i] = __builtin_nontemporal_load(Kp + ((long)blk * 4 + i) * 64);
+        for (int i = 0; i < (KV8 ? 2 : 4); ++i) kr[i] = __builtin_nontemporal_load(Kp + ((long)blk * (KV8 ? 2 : 4) + i) * 64);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vr[i] = __builtin_nontemporal_load(Vp + ((long)blk * 4 + i) * 64);
+        for (int i = 0; i < (KV8 ? 2 : 4); ++i) vr[i] = __builtin_nontemporal_load(Vp + ((long)blk * (KV8 ? 2 : 4) + i) * 64);
     };
-    auto compute = [&](const u32x4 (&kr)[4], const u32x4 (&vr)[4], int blk) {
+    auto compute = [&](const u32x4 (&kr_)[4], const u32x4 (&vr_)[4], int blk) {
+        u32x4 kr[4], vr[4];
+        if (KV8) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 a = fp8x8_to_bf16x8_(kr_[i][0], kr_[i][1]), c2 = fp8x8_to_bf16x8_(kr_[i][2], kr_[i][3]);
+                const bf16x8 v0 = fp8x8_to_bf16x8_(vr_[i][0], vr_[i][1]), v1 = fp8x8_to_bf16x8_(vr_[i][2], vr_[i][3]);
+                kr[2 * i] = *(const u32x4*)&a; kr[2 * i + 1] = *(const u32x4*)&c2; vr[2 * i] = *(const u32x4*)&v0; vr[2 * i + 1] = *(const u32x4*)&v1;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { kr[i] = kr_[i]; vr[i] = vr_[i]; }
+        }
         f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[0], qf0, z4, 0, 0, 0);
         s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[1], qf1, s0, 0, 0, 0);
         f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[2], qf0, z4, 0, 0, 0);
@@ -589,18 +620,20 @@ extern "C" void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, in
     p = &q;
     const dim3 g = persist ? dim3(q.pgrid, 1, 1) : dim3(p->H, b, p->nsplit);
     const size_t sh = (size_t)(lds_pad > 0 ? lds_pad : 0);
+#define LA(NW, PF_) do { if (p->kv8) hipLaunchKernelGGL((dec_attn2_kernel<NW, PF_, 1>), g, dim3(NW * 64), sh, st, *p); else hipLaunchKernelGGL((dec_attn2_kernel<NW, PF_, 0>), g, dim3(NW * 64), sh, st, *p); } while (0)
     switch (variant) {
-        case 20: hipLaunchKernelGGL((dec_attn2_kernel<2, 0>), g, dim3(128), sh, st, *p); break;
-        case 21: hipLaunchKernelGGL((dec_attn2_kernel<2, 1>), g, dim3(128), sh, st, *p); break;
-        case 40: hipLaunchKernelGGL((dec_attn2_kernel<4, 0>), g, dim3(256), sh, st, *p); break;
+        case 20: LA(2, 0); break;
+        case 21: LA(2, 1); break;
+        case 40: LA(4, 0); break;
         // 8 / 16 waves per (sequence, head): the small-batch form — with a handful of sequences ONE launch without split-KV partials and
         // without the combine kernel beats nsplit x 4 waves + combine (one dependent kernel less per layer, experiments/small_chain)
-        case 80: hipLaunchKernelGGL((dec_attn2_kernel<8, 0>), g, dim3(512), sh, st, *p); break;
-        case 81: hipLaunchKernelGGL((dec_attn2_kernel<8, 1>), g, dim3(512), sh, st, *p); break;
-        case 160: hipLaunchKernelGGL((dec_attn2_kernel<16, 0>), g, dim3(1024), sh, st, *p); break;
-        case 161: hipLaunchKernelGGL((dec_attn2_kernel<16, 1>), g, dim3(1024), sh, st, *p); break;
-        default: hipLaunchKernelGGL((dec_attn2_kernel<4, 1>), g, dim3(256), sh, st, *p); break;
+        case 80: LA(8, 0); break;
+        case 81: LA(8, 1); break;
+        case 160: LA(16, 0); break;
+        case 161: LA(16, 1); break;
+        default: LA(4, 1); break;
     }
+#undef LA
     if (p->nsplit > 1 && p->out)
         hipLaunchKernelGGL(dec_attn2_combine_kernel, dim3(p->H, b), dim3(64), 0, st, p->part, p->out, p->H, p->nsplit, p->dim, p->out_packed);
 }
@@ -608,7 +641,7 @@ extern "C" void car_launch_dec_attn2(const Attn2P* p, int b, hipStream_t st) { c
 // =============================================================================================== prefill -> packed cache
 // k/v of the T prefix rows -> packed cache, RoPE on q,k in place (reference: gpt_t2i.py:266-277).  Same arithmetic as
 // decode.hip prefill_rope_kv_kernel; only the cache addressing differs.
-__global__ void prefill_rope_kv2_kernel(bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, const float* rope, int b, int Tn, int H, int dim, int SA) {
+__global__ void prefill_rope_kv2_kernel(bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8) {
     const long total = (long)b * Tn * H * 32;
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -623,16 +656,25 @@ __global__ void prefill_rope_kv2_kernel(bf16_t* qkv, bf16_t* kcache, bf16_t* vca
         row[dim + h * 64 + 2 * pr] = kr0; row[dim + h * 64 + 2 * pr + 1] = kr1;
         const long sb = (bb * H + h) * (long)SA * 64;
         const int d = 2 * pr;
-        bf16_t* kp = kcache + sb + ((long)(t >> 4) * 2 + (d >> 5)) * 512 + ((((d & 31) >> 3) * 16 + (t & 15)) << 3) + (d & 7);
-        kp[0] = kr0; kp[1] = kr1;
         const int w = t & 31, qv = w < 16 ? (w >> 2) : ((w - 16) >> 2), ev = w < 16 ? (w & 3) : (4 + ((w - 16) & 3));
-        bf16_t* vp = vcache + sb + ((long)(t >> 5) * 4 + (d >> 4)) * 512 + ((qv * 16 + (d & 15)) << 3) + ev;
-        vp[0] = row[2 * dim + h * 64 + d]; vp[8] = row[2 * dim + h * 64 + d + 1];
+        if (kv8) {      // e4m3 bytes (K8 / V8 layouts); the prefill's own attention reads the bf16 rows of `qkv`, not the cache
+            const int ek = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(kr0), bf2f(kr1), 0, false);
+            unsigned char* kp = (unsigned char*)kcache + sb + (long)(t >> 4) * 1024 + ((((d & 31) >> 3) * 16 + (t & 15)) << 4) + (d >> 5) * 8 + (d & 7);
+            kp[0] = (unsigned char)(ek & 0xff); kp[1] = (unsigned char)((ek >> 8) & 0xff);
+            const int ev2 = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(row[2 * dim + h * 64 + d]), bf2f(row[2 * dim + h * 64 + d + 1]), 0, false);
+            unsigned char* vp = (unsigned char*)vcache + sb + (long)(t >> 5) * 2048 + (d >> 5) * 1024 + ((qv * 16 + (d & 15)) << 4) + ((d >> 4) & 1) * 8 + ev;
+            vp[0] = (unsigned char)(ev2 & 0xff); vp[16] = (unsigned char)((ev2 >> 8) & 0xff);
+        } else {
+            bf16_t* kp = kcache + sb + ((long)(t >> 4) * 2 + (d >> 5)) * 512 + ((((d & 31) >> 3) * 16 + (t & 15)) << 3) + (d & 7);
+            kp[0] = kr0; kp[1] = kr1;
+            bf16_t* vp = vcache + sb + ((long)(t >> 5) * 4 + (d >> 4)) * 512 + ((qv * 16 + (d & 15)) << 3) + ev;
+            vp[0] = row[2 * dim + h * 64 + d]; vp[8] = row[2 * dim + h * 64 + d + 1];
+        }
     }
 }
-extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, hipStream_t st) {
+extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8, hipStream_t st) {
     long total = (long)b * Tn * H * 32; int g = (int)((total + 255) / 256); if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(prefill_rope_kv2_kernel, dim3(g), dim3(256), 0, st, (bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, rope, b, Tn, H, dim, SA);
+    hipLaunchKernelGGL(prefill_rope_kv2_kernel, dim3(g), dim3(256), 0, st, (bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, rope, b, Tn, H, dim, SA, kv8);
 }
 
 // =============================================================================================== RMSNorm -> packed xn

@@ -43,12 +43,14 @@ struct GemmDP {
     const bf16_t* W; const bf16_t* X; int M, N, K; int w_nt; int f8_mfma; const float* wscale;
     bf16_t* h; bf16_t* outp; float* outf;
     bf16_t* qout; bf16_t* kc; bf16_t* vc; const float* rope; const int* pos; int H, SA, dim;
+    int kv8;
     const bf16_t* nh_in; const bf16_t* nemb; const int* nidx; bf16_t* nh_out; const bf16_t* nw; const bf16_t* nctrl;
     int nadd, nT, n_tok; float ncs, neps;
 };
 struct Attn2P {
     const bf16_t* q; const bf16_t* kc; const bf16_t* vc; const int* pos; const unsigned char* mask; const int* jmin;
     bf16_t* out; float* part; int H, SA, T, dim, nsplit, out_packed;
+    int kv8;
     int n_seq, pgrid;
 };
 struct Norm2P {
@@ -61,7 +63,7 @@ int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st);
 int car_pick_gemm_cfg(int M, int N, int K, int epi);
 void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, int lds_pad, hipStream_t st);
 void car_launch_mask_first_valid(const unsigned char* mask, int* jmin, int b, int T, hipStream_t st);
-void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, hipStream_t st);
+void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8, hipStream_t st);
 void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st);
 void car_launch_build_mask(const int64_t* emb_mask, const int* row_img, unsigned char* out, int b, int T, hipStream_t st);
 // canny.hip
@@ -202,6 +204,7 @@ extern "C" int car_create(car_ctx** out, const car_config* cfg) {
         g_create_err = "car_create: dim, ffn_hidden, caption_dim, vit_hidden, vit_mlp must be multiples of 32"; return -1; }
     if (cfg->decode_weight_fp8 && (cfg->mode != CAR_BF16 || cfg->dim % 64 || cfg->ffn_hidden % 64)) {
         g_create_err = "car_create: decode_weight_fp8 needs CAR_BF16 mode and dim, ffn_hidden multiples of 64"; return -1; }
+    if (cfg->kv_cache_fp8 && cfg->mode != CAR_BF16) { g_create_err = "car_create: kv_cache_fp8 exists only in CAR_BF16 mode (the exact mode is the parity path)"; return -1; }
     if (cfg->vit_hidden % cfg->vit_heads != 0 || (cfg->vit_hidden / cfg->vit_heads) % 32) { g_create_err = "car_create: ViT head_dim must be a multiple of 32"; return -1; }
     int g = (int)std::lround(std::sqrt((double)cfg->block_size));
     if (g * g != cfg->block_size) { g_create_err = "car_create: block_size must be a square (gpt_t2i.py:352)"; return -1; }
@@ -1024,7 +1027,8 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     };
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
-        bf16_t* kc = (bf16_t*)c->kv.p + (size_t)(2 * l) * kv_layer + kv_off; bf16_t* vc = (bf16_t*)c->kv.p + (size_t)(2 * l + 1) * kv_layer + kv_off;
+        const size_t kvb = g.kv_cache_fp8 ? 1 : 2;          // bytes per cached element (e4m3 / bf16)
+        bf16_t* kc = (bf16_t*)((char*)c->kv.p + ((size_t)(2 * l) * kv_layer + kv_off) * kvb); bf16_t* vc = (bf16_t*)((char*)c->kv.p + ((size_t)(2 * l + 1) * kv_layer + kv_off) * kvb);
         if (!fuse_norm) {   // [token gather at layer 0] (+ control add at layers 0, n/3, 2n/3) -> h ; attention_norm -> xn (packed)
             Norm2P np; memset(&np, 0, sizeof(np));
             np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps; np.add = prio ? 2 : 0;
@@ -1035,7 +1039,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             car_launch_rmsnorm2(&np, b, st); ++nk;
         }
         {
-            GemmDP q = z; q.qout = fb.q; q.kc = kc; q.vc = vc; q.rope = c->rope; q.pos = gr.pos; q.H = Hn; q.SA = SA; q.dim = D;
+            GemmDP q = z; q.qout = fb.q; q.kc = kc; q.vc = vc; q.rope = c->rope; q.pos = gr.pos; q.H = Hn; q.SA = SA; q.dim = D; q.kv8 = g.kv_cache_fp8 ? 1 : 0;
             if (fuse_norm) { norm_fields(q, L + "attention_norm.weight", l, true); }
             gemm(L + "attention.wqkv.weight", fb.xn, 3 * D, D, EPI_QKV, q);
             if (fuse_norm && q.nh_out) hc = q.nh_out;
@@ -1044,7 +1048,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         {
             Attn2P ap; memset(&ap, 0, sizeof(ap));
             ap.q = fb.q; ap.kc = kc; ap.vc = vc; ap.pos = gr.pos; ap.mask = maskb ? maskb + (size_t)b0 * T : nullptr; ap.jmin = jmin ? jmin + b0 : nullptr;
-            ap.out = fb.att; ap.part = fb.attn_part; ap.H = Hn; ap.SA = SA; ap.T = T; ap.dim = D; ap.nsplit = nsplit; ap.out_packed = 1;
+            ap.out = fb.att; ap.part = fb.attn_part; ap.H = Hn; ap.SA = SA; ap.T = T; ap.dim = D; ap.nsplit = nsplit; ap.out_packed = 1; ap.kv8 = g.kv_cache_fp8 ? 1 : 0;
             if (gr.attn_pgrid > 0 && nsplit == 1) { ap.n_seq = b; ap.pgrid = gr.attn_pgrid; }
             car_launch_dec_attn2_var(&ap, b, gr.attn_variant, gr.attn_lds_pad, st); nk += nsplit > 1 ? 2 : 1;
         }
@@ -1184,7 +1188,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     // ---- buffers
     const size_t kv_layer = (size_t)b * Hn * SA * 64;
     const size_t kv_cap_before = c->kv.cap;        // ensure() never shrinks: a changed capacity IS a new allocation (the address may repeat)
-    NEED(c, c->kv, (size_t)g.n_layer * 2 * kv_layer * e);
+    const size_t kv_e = (fast && g.kv_cache_fp8) ? 1 : e;        // opt-in e4m3 KV cache: one byte per element
+    NEED(c, c->kv, (size_t)g.n_layer * 2 * kv_layer * kv_e);
     const bool kv_fresh = c->kv.cap != kv_cap_before;
     const long rowsP = (long)b * T;
     NEED(c, c->ws[0], (size_t)b * T * g.caption_dim * e);                     // text input (cond | uncond)
@@ -1288,7 +1293,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             car_launch_rmsnorm(mode, &np, rowsP, st);
         }
         { GemmP q = gp(xn, D, Wp(c, L + "attention.wqkv.weight"), D, qkv, 3 * D, (int)rowsP, 3 * D, D); car_launch_gemm(mode, AMODE_PLAIN, &q, st); }
-        if (fast) car_launch_prefill_rope_kv2(qkv, off(c->kv.p, (size_t)(2 * l) * kv_layer, e), off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e), c->rope, b, T, Hn, D, SA, st);
+        if (fast) car_launch_prefill_rope_kv2(qkv, off(c->kv.p, (size_t)(2 * l) * kv_layer, kv_e), off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, kv_e), c->rope, b, T, Hn, D, SA, g.kv_cache_fp8 ? 1 : 0, st);
         else car_launch_prefill_rope_kv(mode, qkv, off(c->kv.p, (size_t)(2 * l) * kv_layer, e), off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e), c->rope, b, T, Hn, D, S_max, st);
         car_launch_transpose_pad(mode, off(qkv, (size_t)2 * D, e), 3 * D, (long)T * 3 * D, vT, b, T, Tpad, D, st);
         bool fused = false;
@@ -1521,7 +1526,7 @@ extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
         if (c->st_has_mask && c->st_jmin && c->st_b > 0) { (void)hipStreamSynchronize(c->stream); if (hipMemcpy(jm.data(), c->st_jmin, (size_t)c->st_b * 4, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError(); }
         double kvb = 0;
         for (int s = 0; s < c->st_b; ++s)
-            for (int i = 0; i < c->st_nsteps; ++i) { const double p = c->st_T + c->dbg_skip + i; kvb += 2.0 * g.n_layer * g.dim * (double)c->esz * (p + 1 - jm[(size_t)s]); }
+            for (int i = 0; i < c->st_nsteps; ++i) { const double p = c->st_T + c->dbg_skip + i; kvb += 2.0 * g.n_layer * g.dim * ((c->mode == CAR_BF16 && g.kv_cache_fp8) ? 1.0 : (double)c->esz) * (p + 1 - jm[(size_t)s]); }
         c->stats.decode_algo_bytes = (int64_t)(c->st_wbytes * c->st_nsteps + kvb);
     }
     *out = c->stats;

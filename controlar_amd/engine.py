@@ -28,7 +28,7 @@ class Engine:
     """One context = one set of weights in one arithmetic mode ('fp32' exact | 'bf16' fast)."""
 
     def __init__(self, cfg: PathConfig, precision: str = "bf16", device: Optional[torch.device] = None, stream_priority: int = 0,
-                 weights_fp8: bool = False):
+                 weights_fp8: bool = False, kv_fp8: bool = False):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("controlar_amd needs a HIP device (no CPU fallback)")
@@ -59,6 +59,8 @@ class Engine:
         cc.stream_priority = int(stream_priority)
         # BASELINE config 5; bf16 mode only.  True / 1 = weight-only e4m3 (bf16 MFMA); 'mfma' / 2 = W8A8 on the fp8 MFMA
         cc.decode_weight_fp8 = 2 if weights_fp8 in ("mfma", 2) else int(bool(weights_fp8))
+        # opt-in e4m3 KV cache (bf16 mode only; bf16 KV is the default and the parity path): halves the KV stream, doubles the sequences that fit
+        cc.kv_cache_fp8 = int(bool(kv_fp8))
         cc.codebook_size, cc.codebook_dim, cc.z_channels, cc.vq_ch = q.codebook_size, q.codebook_embed_dim, q.z_channels, q.ch
         cc.vq_num_res_blocks, cc.vq_n_mult, cc.gn_eps = q.num_res_blocks, len(q.ch_mult), q.gn_eps
         for i, m in enumerate(q.ch_mult):

@@ -64,7 +64,7 @@ __attribute__((global)) __attribute__((amdgpu_flat_work_group_size(1, 256))) voi
         if (f.op == OP_GEMM) dec_gemm_kernel<I, J, 4, EPI, 0, 0>(f.g);
         else if (f.op == OP_NORM) rmsnorm2_kernel<8>(f.n, f.rows);
     } else {
-        dec_attn2_kernel<4, 0>(f.a);
+        dec_attn2_kernel<4, 0, 0>(f.a);
     }
 }
 

@@ -68,7 +68,11 @@ typedef struct car_config {
                                   per-output-row fp32 scales (BASELINE config 5).  1 = weight-only: bytes widened to bf16 in registers, bf16 MFMA.
                                   2 = W8A8: activations quantised to e4m3 (unit scale, clamped to +-448) in registers and multiplied on the
                                   fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8).  The reference has no fp8 path: tolerance-graded only. */
-    int32_t reserved[3];
+    int32_t kv_cache_fp8;     /* CAR_BF16 only, opt-in (0 = bf16 KV cache: the default and the parity path).  1 = the KV cache holds OCP e4m3fn bytes, unit scale:
+                                  rotated K and V are rounded to e4m3 when they are stored, widened to bf16 in registers in front of the same bf16 MFMAs; the
+                                  prefill's own attention reads the unrounded rows.  Halves the dominant HBM stream of large batches and doubles the sequences
+                                  that fit.  The reference has no such mode: tolerance-graded against the oracle running the same model (kv_fp8=True). */
+    int32_t reserved[2];
 } car_config;
 
 /* sampling parameters — reference: generate.py:59-74 sample(), :134 generate() kwargs */

@@ -240,6 +240,10 @@ class GPTState:
         # model of the library's W8A8 decode mode (car_config.decode_weight_fp8 = 2; NOT a reference feature): the inputs of the five
         # decode linears are rounded to OCP e4m3 (unit scale, clamped to +-448) on single-token steps; the prefill stays as is
         self.act_fp8_decode = False
+        # model of the library's opt-in e4m3 KV cache (car_config.kv_cache_fp8; NOT a reference feature): rotated K and V are rounded to OCP e4m3
+        # (unit scale, clamped to +-448) when they are STORED; the prefill's own attention runs on the unrounded rows it has just computed, every
+        # later step reads the rounded ones
+        self.kv_fp8 = False
 
     def lin(self, x: Tensor, name: str) -> Tensor:
         if self.act_fp8_decode and x.shape[1] == 1:
@@ -279,11 +283,21 @@ def transformer_forward(st: GPTState, h: Tensor, input_pos: Tensor) -> Tensor:
         xq = apply_rope(xq.view(b, s, g.n_head, g.head_dim), fc).transpose(1, 2)
         xk = apply_rope(xk.view(b, s, g.n_head, g.head_dim), fc).transpose(1, 2)
         xv = xv.view(b, s, g.n_head, g.head_dim).transpose(1, 2)
-        st.k[i][:, :, input_pos] = xk
-        st.v[i][:, :, input_pos] = xv
-        sc = (xq.float() @ st.k[i].float().transpose(-1, -2)) * (g.head_dim ** -0.5)
+        if st.kv_fp8:      # library-side model, not the reference: K / V are stored as e4m3; the prefill attends to the rows it has just computed
+            rq = lambda t: t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype)
+            st.k[i][:, :, input_pos] = rq(xk)
+            st.v[i][:, :, input_pos] = rq(xv)
+            kk, vv = st.k[i], st.v[i]
+            if s > 1:
+                kk, vv = kk.clone(), vv.clone()
+                kk[:, :, input_pos] = xk; vv[:, :, input_pos] = xv
+        else:
+            st.k[i][:, :, input_pos] = xk
+            st.v[i][:, :, input_pos] = xv
+            kk, vv = st.k[i], st.v[i]
+        sc = (xq.float() @ kk.float().transpose(-1, -2)) * (g.head_dim ** -0.5)
         sc = sc.masked_fill(~mask, float("-inf"))
-        att = (torch.softmax(sc, dim=-1) @ st.v[i].float()).to(h.dtype)
+        att = (torch.softmax(sc, dim=-1) @ vv.float()).to(h.dtype)
         att = att.transpose(1, 2).reshape(b, s, D)
         h = h + st.lin(att, p + "attention.wo.weight")
         x = rms_norm(h, st.w(p + "ffn_norm.weight"), g.norm_eps)
@@ -325,7 +339,7 @@ def generate(sd, cfg, cond: Tensor, max_new_tokens: int, emb_masks: Optional[Ten
              cfg_scale: float = 1.0, cfg_interval: int = -1, condition: Optional[Tensor] = None,
              control_strength: float = 1.0, dtype=torch.float32, forced_tokens: Optional[Tensor] = None,
              return_logits: bool = False, temperature=1.0, top_k=0, top_p=1.0, sample_logits=False,
-             generator=None, return_stages: bool = False, act_fp8_decode: bool = False):
+             generator=None, return_stages: bool = False, act_fp8_decode: bool = False, kv_fp8: bool = False):
     """reference: generate.py:134-204 (t2i branch) incl. prefill :85-94, decode_one_token :97-110,
     decode_n_tokens :113-131.  ``forced_tokens`` [B,N] switches to the teacher-forced protocol of
     SURVEY.md Appendix G (token fed back = forced token; logits still recorded)."""
@@ -356,6 +370,7 @@ def generate(sd, cfg, cond: Tensor, max_new_tokens: int, emb_masks: Optional[Ten
     s_max = ((T + max_new_tokens + 7) // 8) * 8                                           # gpt_t2i.py:395
     st = GPTState(sd, cfg, b, s_max, dtype)
     st.act_fp8_decode = act_fp8_decode
+    st.kv_fp8 = kv_fp8
     if emb_masks is not None:
         fold_pad_mask(st, torch.cat([emb_masks, emb_masks]) if use_cfg else emb_masks, T)
     # ---- prefill (gpt_t2i.py:433-442): text embed + control-token cache
