@@ -100,7 +100,9 @@ class Transformer:
     def engine(self) -> Engine:
         if self._engine is None:
             prec = "bf16" if self._dtype == torch.bfloat16 else "fp32"
-            self._engine = Engine(self.cfg, prec, device=self._device)
+            # library-side opt-in modes that the reference does not have (tolerance-graded, never the parity path): set e.g.
+            # `gpt.engine_options = {"kv_fp8": True}` (e4m3 KV cache) or `{"weights_fp8": True}` before the first generate()
+            self._engine = Engine(self.cfg, prec, device=self._device, **getattr(self, "engine_options", {}))
             ck = getattr(self, "_ckpt", None)
             if ck is not None:
                 from .checkpoint import load_engine_from_checkpoints
