@@ -313,7 +313,9 @@ def main():
                 and rec.get("image_hw") == [Hh, Ww] and rec.get("adapter_size") == args.adapter_size)
         if not same:
             return None, "no PMC summary for this configuration"
-        return rec["fetch_bytes_per_step"] + rec["write_bytes_per_step"], rec.get("note", "")
+        return (rec["fetch_bytes_per_step"] + rec["write_bytes_per_step"],
+                "NOT measured in this run: read from the committed PMC summary of the same configuration (profiles/pmc_decode_step.json, "
+                "tools/profile_round.sh). " + rec.get("note", ""))
 
     if rank == 0:
         value = G * args.steps / elapsed
