@@ -1497,14 +1497,12 @@ extern "C" int car_sample_logits(car_ctx* c, const float* logits, int32_t B, int
     NEED(c, c->scal, (size_t)(16 + 2 * B) * 4);
     int* stepd = (int*)c->scal.p + 1; int* cur = (int*)c->scal.p + 16;
     fence_in(c, caller);
-    HIPCHK(c, hipMemcpyAsync(stepd, &step, 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));
     SampleP p; memset(&p, 0, sizeof(p));
     p.logits = logits; p.B = B; p.V = V; p.use_cfg = sp->cfg_scale > 1.0f; p.cfg_scale = sp->cfg_scale; p.cfg_interval = sp->cfg_interval;
     p.step_ptr = stepd; p.n_new = 1; p.out_tokens = out; p.cur_tok = cur;
     p.stochastic = sp->sample_logits != 0; p.temperature = sp->temperature; p.top_k = sp->top_k; p.top_p = sp->top_p; p.seed = sp->seed;
     // out_tokens is indexed [i*n_new + step]: n_new = 1 and a zero step pointer keep it dense; the RNG step goes through row0
-    int zero = 0; HIPCHK(c, hipMemcpyAsync(stepd, &zero, 4, hipMemcpyHostToDevice, st)); HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipMemsetAsync(stepd, 0, 4, st));           // no host source buffer, no wait: the entry only enqueues
     p.row0 = step * 65536;
     car_launch_sample_greedy(&p, st);
     fence_out(c, caller);
