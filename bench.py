@@ -51,6 +51,12 @@ def parse():
                          "KV stream of the decode step.  The reference has no such mode; tolerance-graded against the oracle's model of it (tests/test_configs_gpu.py)")
     ap.add_argument("--condition-type", default="canny", help="'canny'/'seg' -> nearest resize, anything else -> bicubic (dinov2_adapter.py:19-23)")
     ap.add_argument("--adapter-size", default="small", choices=["small", "base"])
+    ap.add_argument("--sample-logits", action="store_true",
+                    help="stochastic decoding as every script of the reference runs it (sample_t2i.py:163-170: sample_logits=True, top_k=2000, top_p=1, temperature=1) "
+                         "instead of the greedy parity setting; on-device sampler (top-k / top-p by in-LDS sort, Philox keyed by seed, row, step)")
+    ap.add_argument("--top-k", type=int, default=2000)
+    ap.add_argument("--top-p", type=float, default=1.0)
+    ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--input-dist", default="local", choices=["scatter", "local"],
                     help="N > 1: 'local' = every rank draws its own shard (per-image seeds: the same global batch for any N; no input traffic — the "
@@ -240,13 +246,17 @@ def main():
         emb = torch.stack([synth.text_embeddings(1, T, cap, seed=1234 + rank + world * j)[0][0] for j in range(args.batch)]).to(dev)
     # self-check rows: with >= 4 images the first image of the second half (the second decode chain when the batch is cut in
     # two, engine.hip generate_impl) repeats local image 0 — identical inputs must come out as identical tokens and pixels
-    twin = args.batch // 2 if args.batch >= 4 else -1
+    twin = args.batch // 2 if (args.batch >= 4 and not args.sample_logits) else -1      # sampled rows draw from their own Philox stream (seed, row, step): twins differ by design
     if twin > 0:
         img[twin], emb[twin], mask[twin] = img[0], emb[0], mask[0]
 
     def one_step():
         eng.encode_control(img)
-        toks = eng.generate(emb, n_new, mask, cfg_scale=args.cfg_scale, control_strength=1.0)
+        if args.sample_logits:
+            toks = eng.generate(emb, n_new, mask, cfg_scale=args.cfg_scale, control_strength=1.0, sample_logits=True, top_k=args.top_k, top_p=args.top_p,
+                                temperature=args.temperature, seed=1234)
+        else:
+            toks = eng.generate(emb, n_new, mask, cfg_scale=args.cfg_scale, control_strength=1.0)
         if not args.overlap_vq:
             return toks, vq_eng.vq_decode(toks, gh, gw)
         side.wait_stream(torch.cuda.current_stream())
@@ -286,7 +296,7 @@ def main():
         assert parity["twin_rows_equal"], "identical inputs in two rows of the batch produced different tokens"
     gpath = os.path.join(ROOT, "tests", "golden", "xl_canny_512_cfg1.npz")
     if (rank == 0 and args.model == "xl" and (Hh, Ww) == (512, 512) and args.cfg_scale <= 1.0 and args.adapter_size == "small"
-            and args.condition_type == "canny" and not args.weights_fp8 and not args.kv_fp8 and os.path.exists(gpath)):
+            and args.condition_type == "canny" and not args.weights_fp8 and not args.kv_fp8 and not args.sample_logits and os.path.exists(gpath)):
         # local image 0 of rank 0 is the input of the committed golden (synth seed 1234): the reference's fp32 greedy tokens.
         # The bf16 fast mode free-runs, so it follows them until the first near-tie and is graded teacher-forced in
         # tests/test_bench_shapes_gpu.py; here the common prefix and overall agreement are reported and sanity-bounded.
@@ -329,7 +339,7 @@ def main():
             "config": {"workload": f"LlamaGen-{args.model.upper()} t2i + DINOv2-{args.adapter_size} {args.condition_type} control, {Hh}x{Ww} ({n_new} tokens), "
                                    f"{'fp8 (e4m3) decode weights x e4m3 activations on the fp8 MFMA, ' if args.fp8_mfma else ('fp8 (e4m3) decode weights (weight-only), ' if args.weights_fp8 else '')}"
                                    f"{'OPT-IN e4m3 KV cache (not the reference arithmetic: tolerance-graded mode), ' if args.kv_fp8 else ''}"
-                                   f"cfg_scale={args.cfg_scale}, greedy, {args.batch} images/GPU/step; stages A-H "
+                                   f"cfg_scale={args.cfg_scale}, {('sampled top_k=%d top_p=%g T=%g' % (args.top_k, args.top_p, args.temperature)) if args.sample_logits else 'greedy'}, {args.batch} images/GPU/step; stages A-H "
                                    "(control encoder, generate, VQ decode) all inside the timed region",
                        "images_per_gpu": args.batch, "global_batch": G, "cfg_scale": args.cfg_scale,
                        "per_gpu_images_per_sec": value / world, "parallelism": f"dp{world}",
