@@ -251,7 +251,7 @@ def test_xl_bf16_against_the_oracle_in_bf16_mode():
     eng.close()
 
 
-@pytest.mark.parametrize("size", ["tiny", "xl"])
+@pytest.mark.parametrize("size", ["tiny", "tiny+w8", "xl"])
 def test_e4m3_kv_cache_opt_in(size):
     """car_config.kv_cache_fp8 (opt-in; bf16 KV stays the default and the parity path): rotated K and V are stored as OCP e4m3 bytes, unit scale, and widened
     to bf16 in registers in front of the same MFMAs.  The reference has no such mode: graded teacher-forced against the oracle running the SAME model
@@ -261,6 +261,8 @@ def test_e4m3_kv_cache_opt_in(size):
     from controlar_amd.engine import Engine
     from oracle import controlar_oracle as O
     _threads()
+    w8 = size.endswith("+w8")           # together with e4m3 decode weights (weight-only): the two opt-in modes are independent and compose
+    size = size.split("+")[0]
     if size == "tiny":
         cfg = C.tiny_t2i(64, "canny"); B, H, W, n_new, s_ = 3, 128, 128, 64, 2.0
     else:
@@ -268,9 +270,10 @@ def test_e4m3_kv_cache_opt_in(size):
     gsd, _ = synth.path_state_dicts(cfg, seed=0)
     img = synth.canny_like_control(B, H, W)
     emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
-    toks_o, logits_m = O.generate(gsd, cfg, emb, n_new, mask, cfg_scale=s_, condition=img, return_logits=True, kv_fp8=True)
-    _, logits_p = O.generate(gsd, cfg, emb, n_new, mask, cfg_scale=s_, condition=img, forced_tokens=toks_o, return_logits=True)      # plain model, same tokens
-    eng = Engine(cfg, "bf16", kv_fp8=True); eng.load_state_dict(gsd); eng.finalize()
+    osd = _quantize_like_library(gsd, cfg) if w8 else gsd            # the oracle runs on the dequantised weights in the weight-fp8 combination
+    toks_o, logits_m = O.generate(osd, cfg, emb, n_new, mask, cfg_scale=s_, condition=img, return_logits=True, kv_fp8=True)
+    _, logits_p = O.generate(osd, cfg, emb, n_new, mask, cfg_scale=s_, condition=img, forced_tokens=toks_o, return_logits=True)      # plain model, same tokens
+    eng = Engine(cfg, "bf16", kv_fp8=True, weights_fp8=w8); eng.load_state_dict(gsd); eng.finalize()
     eng.encode_control(img.cuda())
     toks, logits = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=s_, forced_tokens=toks_o, return_logits=True)
     assert eng.stats()["graph_used"]
@@ -280,7 +283,7 @@ def test_e4m3_kv_cache_opt_in(size):
     model = (logits_m - logits_p).abs()             # what the model itself moves
     k = 1.0 if s_ <= 1 else float(np.sqrt(s_ ** 2 + (s_ - 1) ** 2))
     agree = (toks.cpu() == toks_o)
-    _record(f"kv_e4m3[{size}]", hip_vs_model_max=float(d.max()), hip_vs_model_mean=float(d.mean()), model_vs_plain_max=float(model.max()),
+    _record(f"kv_e4m3[{size}{'+w8' if w8 else ''}]", hip_vs_model_max=float(d.max()), hip_vs_model_mean=float(d.mean()), model_vs_plain_max=float(model.max()),
             model_vs_plain_mean=float(model.mean()), argmax_agreement=float(agree.float().mean()))
     if size == "tiny":
         # the model rounds the same bf16-exact... no: the oracle rounds fp32 K / V, HIP rounds their bf16 values — an e4m3 code can differ where the two disagree by a bf16
