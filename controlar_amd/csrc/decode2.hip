@@ -42,35 +42,7 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {          // v_cvt_pk_
     return *(const unsigned*)&r;
 }
 
-#define CAR_GEMMDP_DEFINED
-enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
-
-struct GemmDP {
-    const bf16_t* W;      // packed [N/16][K/32][64][8]
-    const bf16_t* X;      // packed [ceil(M/16)][K/32][64][8]
-    int M, N, K;
-    int w_nt;             // bit 0: stream W with the non-temporal policy (single M tile: each byte is used once); bit 1: raise the wave priority (s_setprio 3)
-    int f8_mfma;          // F8 kernels: 1 = quantise the X fragments to e4m3 in registers and multiply on v_mfma_f32_16x16x32_fp8_fp8 (W8A8), 0 = widen W to bf16
-    const float* wscale;  // F8 kernels: per-output-row fp32 scale of the e4m3 weight image [N/16][K/64][64][16 B] (engine.hip upload_packed_fp8)
-    // EPI_RESID: h[m][n] (row-major, ld = N) updated in place
-    bf16_t* h;
-    // EPI_SWIGLU: packed [ceil(M/16)][(N/2)/32][64][8]
-    bf16_t* outp;
-    // EPI_LOGITS: fp32 [M][N]
-    float* outf;
-    // EPI_QKV
-    bf16_t* qout;         // [M][H][64] rotated q, pre-scaled by head_dim^-0.5
-    bf16_t* kc; bf16_t* vc;   // packed caches of this layer, already offset to the chain's first sequence
-    const float* rope;    // [n_pos][32][2]
-    const int* pos;
-    int H, SA, dim;
-    int kv8;              // EPI_QKV: K / V rows are stored as OCP e4m3 bytes (K8 / V8 layouts above) instead of bf16
-    // NORM kernels (M <= 16): X = RMSNorm of the residual stream, computed in the prologue of every workgroup (K = model dim):
-    //   v = gather ? emb[idx[m]] : h_in[m] ; (+ control token at *pos, gpt_t2i.py:466) ; workgroup 0 stores v to h_out if set ;
-    //   x = rnd(rnd(v * rsqrt(mean v^2 + eps)) * w)     — the arithmetic of rmsnorm2_kernel, gpt_t2i.py:193-198
-    const bf16_t* nh_in; const bf16_t* nemb; const int* nidx; bf16_t* nh_out; const bf16_t* nw; const bf16_t* nctrl;
-    int nadd, nT, n_tok; float ncs, neps;
-};
+#include "decode2_params.h"
 
 // OCP e4m3fn bytes -> bf16 (exact: e4m3 is a subset of bf16).  lo/hi: 4 bytes each = 8 consecutive k of one row.
 // v_cvt_scalef32_pk_bf16_fp8 (gfx950): two bytes -> a packed bf16 pair in ONE instruction (scale 1.0); four per fragment where the
@@ -406,19 +378,6 @@ extern "C" void car_launch_dec_gemm(const GemmDP* p, int epi, hipStream_t st) {
 }
 
 // =============================================================================================== attention
-struct Attn2P {
-    const bf16_t* q;            // [b][H][64] rotated, pre-scaled (EPI_QKV)
-    const bf16_t* kc; const bf16_t* vc;   // packed caches of this layer (chain base)
-    const int* pos;             // device scalar: the new token's position (its K/V row is already in the cache)
-    const unsigned char* mask;  // [b][T] text-pad mask or null
-    const int* jmin;            // [b] first attendable text position per sequence (car_launch_mask_first_valid) or null
-    bf16_t* out;                // nsplit == 1: attention output, XP-packed [ceil(b/16)][dim/32][64][8] if out_packed else [b][dim]
-    float* part;                // nsplit > 1: [b][H][nsplit][66] (m, l, o[64])
-    int H, SA, T, dim, nsplit, out_packed;
-    int kv8;                    // the caches hold e4m3 bytes (K8 / V8 layouts), widened to bf16 in registers
-    int n_seq, pgrid;           // persistent form (nsplit == 1): n_seq > 0 sequences, a 1-D grid of pgrid workgroups walks the n_seq*H items
-};
-
 // NWAVE waves share one (sequence, head): wave w of split s takes 32-position blocks blk0 + s*NWAVE + w, stride nsplit*NWAVE.
 // PF = 1 keeps the next block's 8 KiB in flight in a second register set while the current one is consumed.
 template <int NWAVE, int PF, int KV8>
@@ -680,11 +639,6 @@ extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const
 // =============================================================================================== RMSNorm -> packed xn
 // Same arithmetic as ops.hip rmsnorm_kernel<bf16_t> (gpt_t2i.py:193-198, :445, :463/:466) without the split-K residual
 // branch; xn is written in the XP layout that dec_gemm consumes.
-struct Norm2P {
-    const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
-    const bf16_t* ctrl; const int* pos; int add /* bit 0: add the control token, bit 1: raised wave priority */; int T; int n_tok; float cs;
-    int D; float eps;
-};
 // one WAVE per row (4 rows per workgroup): a decode-step row is 2.5 KB, so the kernel is pure latency — no LDS, no barrier,
 // the sum of squares folds through wave shuffles in a fixed order.  Lane l owns column groups l, l+64, ... (4 columns each).
 template <int NQ>

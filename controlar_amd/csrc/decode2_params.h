@@ -1,0 +1,55 @@
+// decode2_params.h — the parameter blocks of the decode-step kernels (decode2.hip), shared with their only caller (engine.hip) and with the standalone
+// harnesses under experiments/: ONE definition, so a field added on one side cannot silently shift the layout the other side fills.
+#pragma once
+#include "car_common.h"
+
+#define CAR_GEMMDP_DEFINED
+enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
+
+struct GemmDP {
+    const bf16_t* W;      // packed [N/16][K/32][64][8]
+    const bf16_t* X;      // packed [ceil(M/16)][K/32][64][8]
+    int M, N, K;
+    int w_nt;             // bit 0: stream W with the non-temporal policy (single M tile: each byte is used once); bit 1: raise the wave priority (s_setprio 3)
+    int f8_mfma;          // F8 kernels: 1 = quantise the X fragments to e4m3 in registers and multiply on v_mfma_f32_16x16x32_fp8_fp8 (W8A8), 0 = widen W to bf16
+    const float* wscale;  // F8 kernels: per-output-row fp32 scale of the e4m3 weight image [N/16][K/64][64][16 B] (engine.hip upload_packed_fp8)
+    // EPI_RESID: h[m][n] (row-major, ld = N) updated in place
+    bf16_t* h;
+    // EPI_SWIGLU: packed [ceil(M/16)][(N/2)/32][64][8]
+    bf16_t* outp;
+    // EPI_LOGITS: fp32 [M][N]
+    float* outf;
+    // EPI_QKV
+    bf16_t* qout;         // [M][H][64] rotated q, pre-scaled by head_dim^-0.5
+    bf16_t* kc; bf16_t* vc;   // packed caches of this layer, already offset to the chain's first sequence
+    const float* rope;    // [n_pos][32][2]
+    const int* pos;
+    int H, SA, dim;
+    int kv8;              // EPI_QKV: K / V rows are stored as OCP e4m3 bytes (K8 / V8 layouts above) instead of bf16
+    // NORM kernels (M <= 16): X = RMSNorm of the residual stream, computed in the prologue of every workgroup (K = model dim):
+    //   v = gather ? emb[idx[m]] : h_in[m] ; (+ control token at *pos, gpt_t2i.py:466) ; workgroup 0 stores v to h_out if set ;
+    //   x = rnd(rnd(v * rsqrt(mean v^2 + eps)) * w)     — the arithmetic of rmsnorm2_kernel, gpt_t2i.py:193-198
+    const bf16_t* nh_in; const bf16_t* nemb; const int* nidx; bf16_t* nh_out; const bf16_t* nw; const bf16_t* nctrl;
+    int nadd, nT, n_tok; float ncs, neps;
+};
+
+// =============================================================================================== attention
+struct Attn2P {
+    const bf16_t* q;            // [b][H][64] rotated, pre-scaled (EPI_QKV)
+    const bf16_t* kc; const bf16_t* vc;   // packed caches of this layer (chain base)
+    const int* pos;             // device scalar: the new token's position (its K/V row is already in the cache)
+    const unsigned char* mask;  // [b][T] text-pad mask or null
+    const int* jmin;            // [b] first attendable text position per sequence (car_launch_mask_first_valid) or null
+    bf16_t* out;                // nsplit == 1: attention output, XP-packed [ceil(b/16)][dim/32][64][8] if out_packed else [b][dim]
+    float* part;                // nsplit > 1: [b][H][nsplit][66] (m, l, o[64])
+    int H, SA, T, dim, nsplit, out_packed;
+    int kv8;                    // the caches hold e4m3 bytes (K8 / V8 layouts), widened to bf16 in registers
+    int n_seq, pgrid;           // persistent form (nsplit == 1): n_seq > 0 sequences, a 1-D grid of pgrid workgroups walks the n_seq*H items
+};
+
+// =============================================================================================== RMSNorm -> packed xn
+struct Norm2P {
+    const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
+    const bf16_t* ctrl; const int* pos; int add /* bit 0: add the control token, bit 1: raised wave priority */; int T; int n_tok; float cs;
+    int D; float eps;
+};

@@ -37,27 +37,8 @@ struct AttnP {
     void* out; float* part; int H, S_max, T, dim, nsplit;
     const float* qkv_parts; int qkv_ks; long qkv_stride;
 };
-// decode2.hip
-enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
-struct GemmDP {
-    const bf16_t* W; const bf16_t* X; int M, N, K; int w_nt; int f8_mfma; const float* wscale;
-    bf16_t* h; bf16_t* outp; float* outf;
-    bf16_t* qout; bf16_t* kc; bf16_t* vc; const float* rope; const int* pos; int H, SA, dim;
-    int kv8;
-    const bf16_t* nh_in; const bf16_t* nemb; const int* nidx; bf16_t* nh_out; const bf16_t* nw; const bf16_t* nctrl;
-    int nadd, nT, n_tok; float ncs, neps;
-};
-struct Attn2P {
-    const bf16_t* q; const bf16_t* kc; const bf16_t* vc; const int* pos; const unsigned char* mask; const int* jmin;
-    bf16_t* out; float* part; int H, SA, T, dim, nsplit, out_packed;
-    int kv8;
-    int n_seq, pgrid;
-};
-struct Norm2P {
-    const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
-    const bf16_t* ctrl; const int* pos; int add; int T; int n_tok; float cs;
-    int D; float eps;
-};
+// decode2.hip: parameter blocks shared through one header
+#include "decode2_params.h"
 extern "C" {
 int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st);
 int car_pick_gemm_cfg(int M, int N, int K, int epi);
