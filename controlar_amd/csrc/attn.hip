@@ -15,18 +15,7 @@
 // Rounding points (fast mode): scores stay fp32 (as the fused SDPA kernels the reference runs), probabilities are rounded to bf16
 // before P·V, the output is rounded once.  T5 mode reproduces the eager op sequence rnd(rnd(q·k) + bias).
 #include "car_common.h"
-
-struct FlashP {
-    const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* o;
-    long q_sb, q_st, k_sb, k_st;      // batch / token strides in elements; head h starts at column h*64
-    long vt_sb; int vt_ld;            // V^T [b][h*64 + d][vt_ld] (keys zero padded to a multiple of 32)
-    long o_sb, o_st;
-    int Tq, Tk, H;
-    float scale;
-    int mode;                         // 0 none | 1 causal + pad mask: key j allowed iff j <= i and (mask[b][j] or j == i) | 2 bias + key mask (T5)
-    const unsigned char* mask;        // [b][Tk]
-    const float* bias;                // [H][Tq][Tk]
-};
+#include "kernel_params.h"
 
 #define FA_KLD 72      // K tile row stride (elements): 144 B keeps the 16-byte fragment reads of 16 rows on distinct banks
 #define FA_VLD 40      // V^T tile row stride: 80 B

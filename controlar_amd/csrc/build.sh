@@ -10,7 +10,7 @@ BID=$(cat *.hip *.h ../../include/controlar_hip.h | sha1sum | cut -c1-40)
 if [ ! -f _obj/build_id.h ] || ! grep -q "$BID" _obj/build_id.h; then echo "#define CAR_BUILD_ID \"$BID\"" > _obj/build_id.h; fi
 pids=()
 for f in gemm ops decode decode2 pack canny t5 attn engine; do
-  if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ car_common.h -nt _obj/$f.o ] || [ decode2_params.h -nt _obj/$f.o ] || { [ $f = engine ] && [ _obj/build_id.h -nt _obj/$f.o ]; } || [ ../../include/controlar_hip.h -nt _obj/$f.o ]; then
+  if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ car_common.h -nt _obj/$f.o ] || [ decode2_params.h -nt _obj/$f.o ] || [ kernel_params.h -nt _obj/$f.o ] || { [ $f = engine ] && [ _obj/build_id.h -nt _obj/$f.o ]; } || [ ../../include/controlar_hip.h -nt _obj/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o _obj/$f.o &
     pids+=($!)
   fi

@@ -9,18 +9,7 @@
 // Layout: K/V cache [b, head, S_max, 64] of T — one (b, head) stream is contiguous, so a wave
 // instruction reads 1 KiB of consecutive rows with 16 B per lane (fully coalesced).
 #include "car_common.h"
-
-struct AttnP {
-    const void* qkv;        // [b, 3*dim] T, raw wqkv output (q | k | v)
-    void* kcache; void* vcache;   // [b, H, S_max, 64] T (this layer)
-    const float* rope;      // [n_pos, 32, 2] fp32 (cos, sin); rows < T are zero (gpt_t2i.py:518)
-    const int* pos;         // device scalar: input_pos p
-    const unsigned char* emb_mask;  // [b, T] (text-pad mask, already duplicated for the CFG half) or null
-    void* out;              // [b, dim] T                        (nsplit == 1)
-    float* part;            // [b, H, nsplit, 66] fp32 (m, l, o[64]) (nsplit > 1)
-    int H, S_max, T, dim, nsplit;
-    const float* qkv_parts; int qkv_ks; long qkv_stride;   // fast path: wqkv output as fp32 split-K partials [ks][b][3*dim]
-};
+#include "kernel_params.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <typename T> struct VecT;

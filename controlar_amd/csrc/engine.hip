@@ -17,28 +17,9 @@
 #include <unordered_map>
 #include <vector>
 
-// ---- launchers implemented in gemm.hip / ops.hip / decode.hip
-struct NormP {
-    const void* h_in; const void* emb; const int* idx; void* h_out; void* xn; const void* w;
-    const void* ctrl; const int* pos; int add_mode; int T; int n_tok; float cs;
-    int D; float eps;
-    const float* parts; int parts_ks; long parts_stride;
-};
-struct SampleP {
-    const float* logits; int B, V, use_cfg; float cfg_scale; int cfg_interval;
-    const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
-    int logits_ks; long logits_stride; int round_bf16;
-    int stochastic; float temperature; int top_k; float top_p; unsigned long long seed; int row0;
-    const struct SampleDyn* dyn;
-};
-struct SampleDyn { unsigned long long seed; float temperature; int top_k; float top_p; int pad; };
-struct AttnP {
-    const void* qkv; void* kcache; void* vcache; const float* rope; const int* pos; const unsigned char* emb_mask;
-    void* out; float* part; int H, S_max, T, dim, nsplit;
-    const float* qkv_parts; int qkv_ks; long qkv_stride;
-};
 // decode2.hip: parameter blocks shared through one header
 #include "decode2_params.h"
+#include "kernel_params.h"
 extern "C" {
 int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st);
 int car_pick_gemm_cfg(int M, int N, int K, int epi);
@@ -60,11 +41,6 @@ void car_launch_t5_prep(const long long* ids, const long long* mask, int* ids32,
 void car_launch_t5_softmax(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, const float* bias,
                            const unsigned char* mask, int Tq, int n_head, hipStream_t st);
 void car_launch_t5_gated_act(int mode, const void* in, void* out, long rows, int hidden, hipStream_t st);
-struct FlashP {
-    const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* o;
-    long q_sb, q_st, k_sb, k_st; long vt_sb; int vt_ld; long o_sb, o_st;
-    int Tq, Tk, H; float scale; int mode; const unsigned char* mask; const float* bias;
-};
 int car_launch_flash64(const FlashP* p, int B, hipStream_t st);
 void car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);
 int car_conv3_halo64_ok(int mode, const GemmP* p);

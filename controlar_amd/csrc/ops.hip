@@ -4,6 +4,7 @@
 // untyped pointers, reduce in fp32 with wave64 shuffles in a fixed order (deterministic), and
 // round where the reference's torch ops round.
 #include "car_common.h"
+#include "kernel_params.h"
 
 #define LAUNCH_T(mode, KERNEL, grid, block, st, ...)                                          \
     do {                                                                                      \
@@ -95,19 +96,6 @@ extern "C" void car_launch_layernorm(int mode, const void* x, const void* w, con
     LAUNCH_T(mode, layernorm_kernel, dim3(rows), dim3(128), st, x, w, b, y, D, eps);
 }
 
-// ------------------------------------------------------------------ RMSNorm with optional token gather and control add
-// reference: gpt_t2i.py:193-198 (norm), :445 (tok_embeddings gather), :463/:466 (control add)
-//   row r:  v = gather ? emb[idx[r]] : h_in[r]
-//           parts: v = rnd(v + rnd(sum_s parts[s][r]))   (residual add of a dec_linear output, decode fast path)
-//           add_mode 1 (decode):  v = rnd(v + rnd(cs * ctrl[r, *pos - T + 1]))
-//           add_mode 2 (prefill): same with control token 0, only on rows r % T == T-1 (ctrl batch = r / T)
-//           h_out[r] = v (if h_out);  xn[r] = rnd(rnd(v * rsqrt(mean(v^2)+eps)) * w)
-struct NormP {
-    const void* h_in; const void* emb; const int* idx; void* h_out; void* xn; const void* w;
-    const void* ctrl; const int* pos; int add_mode; int T; int n_tok; float cs;
-    int D; float eps;
-    const float* parts; int parts_ks; long parts_stride;   // residual branch as fp32 split-K partials [ks][rows][D] of dec_linear
-};
 template <typename T>
 __device__ inline void ld4(const T* p, float (&v)[4]);
 template <> __device__ inline void ld4<float>(const float* p, float (&v)[4]) { const float4 u = *(const float4*)p; v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
@@ -687,19 +675,6 @@ extern "C" void car_launch_swiglu_parts(const float* parts, int ks, long stride,
     hipLaunchKernelGGL(swiglu_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, st, parts, ks, stride, (bf16_t*)out, rows, hidden);
 }
 
-// ------------------------------------------------------------------ CFG mix + greedy argmax (generate.py:90,105; :59-74 greedy branch)
-// logits fp32 [b, V] (cond rows [0,B), uncond rows [B,2B)).  One block per image.
-//   mixed = use_mix ? u + (c - u) * scale : c;  token = lowest index of the maximum (torch.topk tie rule)
-// writes: out_tokens[i*n_new + step], cur_tok[i] (and cur_tok[B+i] under CFG) = forced ? forced[i*n_new+step] : token,
-// optional logits_out[(i*n_new + step)*V + :] = mixed.
-struct SampleP {
-    const float* logits; int B, V, use_cfg; float cfg_scale; int cfg_interval;
-    const int* step_ptr; int n_new; int* out_tokens; int* cur_tok; const int* forced; float* logits_out;
-    int logits_ks; long logits_stride; int round_bf16;   // logits given as split-K partials [ks][b][V]; bf16 rounding of the sum (gpt_t2i.py:470)
-    int stochastic; float temperature; int top_k; float top_p; unsigned long long seed; int row0;   // sample_logits=True path (generate.py:59-74)
-    const struct SampleDyn* dyn;    // when set, (seed, temperature, top_k, top_p) are read from device memory: a captured graph stays valid across calls
-};
-struct SampleDyn { unsigned long long seed; float temperature; int top_k; float top_p; int pad; };
 // 4 consecutive logits of `row` starting at column j (V % 4 == 0)
 __device__ inline void sample_logit4(const SampleP& p, long row, int j, float (&v)[4]) {
     if (p.logits_ks <= 0) { const float4 u = *(const float4*)(p.logits + row * p.V + j); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; return; }
