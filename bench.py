@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=768, help="images per GPU per step (768 sequences = 163 GB of bf16 KV cache in two chains of 384: sized for the 288 GB of one MI355X; measured plateau, profiles/r02_decode_batch_sweep.txt)")
     ap.add_argument("--cfg-scale", type=float, default=1.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--model", default="xl", choices=["xl", "b", "tiny"])
+    ap.add_argument("--model", default="xl", choices=["xl", "b", "tiny", "b_c2i", "l_c2i"])
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--image-h", type=int, default=0, help="non-square (MR) height; token grid = H/16 x W/16, rope grid = max side (sample_t2i_MR.py:73-78)")
     ap.add_argument("--image-w", type=int, default=0)
@@ -67,10 +67,15 @@ def parse():
                     help="run the VQ decode of batch i on a side stream under the token loop of batch i+1 (measured: no gain on MI355X — "
                          "the token loop is HBM-bound and the decoder's GEMM grids take every CU; kept for experiments)")
     ap.add_argument("--cpu-tokens", type=int, default=48, help="decode tokens timed by the CPU baseline sample")
-    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
-                    help="one of BASELINE.json's other configs (SURVEY §8d'): 2 = cfg 4 batch 1; 3 = DINOv2-base depth cfg 4, 32 images/GPU; "
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="one of BASELINE.json's other configs (SURVEY §8d'): 1 = LlamaGen-B c2i 256x256 class-conditional + ViT-S/16 control, cfg 1, 4 images (the reference's "
+                         "CPU-runnable case); 2 = cfg 4 batch 1; 3 = DINOv2-base depth cfg 4, 32 images/GPU; "
                          "4 = MR 768x512 cfg 4 batch 1; 5 = edge_base fp8 weights batch 8.  0 = the headline metric config")
     a = ap.parse_args()
+    if a.config == 1:
+        a.model, a.image_size, a.cfg_scale = "b_c2i", 256, 1.0
+        if a.batch == 768:
+            a.batch = 4                                   # the reference's four fixtures (sample_c2i.py:96-106)
     if a.config == 2:
         a.cfg_scale, a.batch = 4.0, 1
     elif a.config == 3:
@@ -126,7 +131,10 @@ def cpu_baseline(cfg, gsd, vsd, H, W, n_tok_sample):
     torch.set_num_threads(cores)
     log(f"cpu baseline on {cores} threads (GEMV probe {134.2e6 / best[1] / 1e9:.1f} GB/s)")
     img = synth.canny_like_control(1, H, W)
-    emb, mask = synth.text_embeddings(1, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    if cfg.gpt.model_type == "c2i":
+        emb, mask = synth.class_labels(1, cfg.gpt.num_classes), None      # class label instead of caption features (gpt.py), no pad mask
+    else:
+        emb, mask = synth.text_embeddings(1, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
     n_full = (H // 16) * (W // 16)
     t0 = time.perf_counter()
     a = O.control_encoder(gsd, cfg, img)
@@ -193,7 +201,10 @@ def main():
     Hh, Ww = (args.image_h or S), (args.image_w or S)
     gh, gw = Hh // 16, Ww // 16
     grid = max(gh, gw)
-    if args.model == "tiny":
+    c2i = args.model.endswith("_c2i")
+    if c2i:                                                   # gpt.py: class-label prefix of length 1, ViT-S/16 control encoder, no text, no pad mask
+        cfg = {"b_c2i": C.b_c2i, "l_c2i": C.l_c2i}[args.model](grid * grid)
+    elif args.model == "tiny":
         cfg = C.tiny_t2i(grid * grid, args.condition_type)
     else:
         cfg = {"xl": C.xl_t2i, "b": C.b_t2i}[args.model](grid * grid, adapter_size=args.adapter_size, condition_type=args.condition_type)
@@ -224,8 +235,11 @@ def main():
                 h_img[j] = synth.canny_like_control(1, Hh, Ww, seed=1234 + g_, dtype=torch.bfloat16)[0]             # {-1,+1}: exact in bf16
             else:
                 h_img[j] = synth.smooth_control(1, Hh, Ww, seed=1234 + g_)[0].to(torch.bfloat16)
-            e_, m_ = synth.text_embeddings(1, T, cap, seed=1234 + g_)
-            h_emb[j] = e_[0].to(torch.bfloat16); h_mask[j] = m_[0]
+            if c2i:                                           # class-conditional: no caption features (the class labels are drawn below)
+                h_emb[j] = 0; h_mask[j] = 1
+            else:
+                e_, m_ = synth.text_embeddings(1, T, cap, seed=1234 + g_)
+                h_emb[j] = e_[0].to(torch.bfloat16); h_mask[j] = m_[0]
         for j in range(args.batch):
             one(j)
         return packed
@@ -240,7 +254,7 @@ def main():
     t_bcast = time.perf_counter() - t_bc0                     # host synthesis of the shards + H2D + the point-to-point sends
     shard_bytes = int(sum(__import__("controlar_amd.dist", fromlist=["packed_layout"]).packed_layout(args.batch, Hh, Ww, T, cap)))
     img, emb, mask = img.contiguous(), emb.contiguous(), mask.contiguous()
-    if args.precision == "fp32":
+    if args.precision == "fp32" and not c2i:
         # exact mode takes the caption features in fp32 (the packed transport buffer carries bf16): redraw this rank's rows unrounded,
         # so that row 0 is bit for bit the input of the committed XL golden (the control maps are {-1,+1}: exact in either type)
         emb = torch.stack([synth.text_embeddings(1, T, cap, seed=1234 + rank + world * j)[0][0] for j in range(args.batch)]).to(dev)
@@ -250,8 +264,18 @@ def main():
     if twin > 0:
         img[twin], emb[twin], mask[twin] = img[0], emb[0], mask[0]
 
+    labels = None
+    if c2i:
+        labels = torch.stack([synth.class_labels(1, cfg.gpt.num_classes, seed=1234 + rank + world * j)[0] for j in range(args.batch)]).to(dev)
+        if twin > 0:
+            labels[twin] = labels[0]
+
     def one_step():
         eng.encode_control(img)
+        if c2i:
+            toks = eng.generate(labels, n_new, None, cfg_scale=args.cfg_scale, sample_logits=args.sample_logits, top_k=(args.top_k if args.sample_logits else 0),
+                                top_p=args.top_p, temperature=args.temperature, seed=1234)
+            return toks, vq_eng.vq_decode(toks, gh, gw)
         if args.sample_logits:
             toks = eng.generate(emb, n_new, mask, cfg_scale=args.cfg_scale, control_strength=1.0, sample_logits=True, top_k=args.top_k, top_p=args.top_p,
                                 temperature=args.temperature, seed=1234)
@@ -336,7 +360,8 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"LlamaGen-{args.model.upper()} t2i + DINOv2-{args.adapter_size} {args.condition_type} control, {Hh}x{Ww} ({n_new} tokens), "
+            "config": {"workload": (f"LlamaGen-{args.model[0].upper()} c2i (class-conditional, gpt.py) + ViT-S/16 canny control, {Hh}x{Ww} ({n_new} tokens), " if c2i else
+                                    f"LlamaGen-{args.model.upper()} t2i + DINOv2-{args.adapter_size} {args.condition_type} control, {Hh}x{Ww} ({n_new} tokens), ") +
                                    f"{'fp8 (e4m3) decode weights x e4m3 activations on the fp8 MFMA, ' if args.fp8_mfma else ('fp8 (e4m3) decode weights (weight-only), ' if args.weights_fp8 else '')}"
                                    f"{'OPT-IN e4m3 KV cache (not the reference arithmetic: tolerance-graded mode), ' if args.kv_fp8 else ''}"
                                    f"cfg_scale={args.cfg_scale}, {('sampled top_k=%d top_p=%g T=%g' % (args.top_k, args.top_p, args.temperature)) if args.sample_logits else 'greedy'}, {args.batch} images/GPU/step; stages A-H "
