@@ -1,0 +1,67 @@
+"""CPU checks of the library-side opt-in MODELS as the oracle states them (what the GPU tests grade the HIP kernels against) and of bench.py's
+configuration presets.  No GPU, no /root/reference."""
+import sys
+
+import pytest
+import torch
+
+from controlar_amd import config as C, synth
+from oracle import controlar_oracle as O
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = C.tiny_t2i(64, "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    B = 2
+    img = synth.canny_like_control(B, 128, 128)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    return cfg, gsd, img, emb, mask
+
+
+def test_e4m3_kv_model_rounds_at_store_time_only(tiny):
+    """kv_fp8=True (car_config.kv_cache_fp8): K / V are rounded to e4m3 when STORED; the prefill attends to the rows it has just computed, so the first
+    sampled token's logits are untouched; every later step reads rounded rows, so its logits move — a little (3 mantissa bits on O(1) values)."""
+    cfg, gsd, img, emb, mask = tiny
+    t0, l0 = O.generate(gsd, cfg, emb, 12, mask, condition=img, return_logits=True)
+    t1, l1 = O.generate(gsd, cfg, emb, 12, mask, condition=img, return_logits=True, forced_tokens=t0, kv_fp8=True)
+    assert torch.equal(l0[:, 0], l1[:, 0])                               # prefill step: identical
+    d = (l0[:, 1:] - l1[:, 1:]).abs()
+    assert float(d.max()) > 0 and float(d.max()) < 0.25 and float(d.mean()) < 0.03, (float(d.max()), float(d.mean()))
+    t2, l2 = O.generate(gsd, cfg, emb, 12, mask, condition=img, return_logits=True, forced_tokens=t0, kv_fp8=True)
+    assert torch.equal(l1, l2)                                           # deterministic
+    # the stored rows really are e4m3 values: rounding them again changes nothing
+    k = torch.randn(4, 64) * 3
+    r = k.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    assert torch.equal(r, r.to(torch.float8_e4m3fn).float())
+
+
+def test_w8a8_model_rounds_decode_linear_inputs_only(tiny):
+    """act_fp8_decode=True (decode_weight_fp8 = 2): inputs of the decode linears are rounded to e4m3 on single-token steps; the prefill is untouched."""
+    cfg, gsd, img, emb, mask = tiny
+    t0, l0 = O.generate(gsd, cfg, emb, 8, mask, condition=img, return_logits=True)
+    _, l1 = O.generate(gsd, cfg, emb, 8, mask, condition=img, return_logits=True, forced_tokens=t0, act_fp8_decode=True)
+    assert torch.equal(l0[:, 0], l1[:, 0])
+    assert float((l0[:, 1:] - l1[:, 1:]).abs().max()) > 0
+
+
+def test_bench_config_presets(monkeypatch):
+    """bench.py --config N maps to the BASELINE.json configurations of SURVEY §8d' (1 = the c2i model, new in round 3)."""
+    import importlib
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+
+    def args(*a):
+        monkeypatch.setattr(sys, "argv", ["bench.py", *a])
+        return bench.parse()
+    a = args()
+    assert (a.model, a.batch, a.cfg_scale, a.precision, a.gpus, a.input_dist) == ("xl", 768, 1.0, "bf16", 1, "local") and not a.kv_fp8 and not a.sample_logits
+    a = args("--config", "1")
+    assert (a.model, a.batch, a.image_size, a.cfg_scale) == ("b_c2i", 4, 256, 1.0)
+    assert args("--config", "1", "--batch", "1024").batch == 1024
+    a = args("--config", "2"); assert (a.cfg_scale, a.batch) == (4.0, 1)
+    a = args("--config", "3"); assert (a.cfg_scale, a.batch, a.condition_type, a.adapter_size) == (4.0, 32, "depth", "base")
+    a = args("--config", "4"); assert (a.cfg_scale, a.batch, a.image_h, a.image_w) == (4.0, 1, 768, 512)
+    a = args("--config", "5"); assert (a.batch, a.fp8_mfma, a.weights_fp8, a.adapter_size) == (8, True, True, "base")
+    a = args("--gpus", "8", "--steps", "20", "--warmup", "5"); assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
