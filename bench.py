@@ -39,7 +39,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=768, help="images per GPU per step (768 sequences = 163 GB of bf16 KV cache in two chains of 384: sized for the 288 GB of one MI355X; measured plateau, profiles/r02_decode_batch_sweep.txt)")
     ap.add_argument("--cfg-scale", type=float, default=1.0)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="fp32 = the exact mode: greedy tokens bit-identical to the reference's fp32 CPU path (`--precision none` of sample_t2i.py:197); "
+                         "decode linears on the exact fp32 MFMA (decode_f32.hip); batch defaults to 384 (fp32 KV cache = 162 GB)")
+    ap.add_argument("--vq-precision", default=None, choices=["bf16", "fp32"],
+                    help="arithmetic of the VQ decoder context (the reference keeps vq_model a separate module).  Default: bf16 — north_star grades pixels by "
+                         "tolerance and tokens bit-exactly, so `--precision fp32` alone is the tokens-exact configuration; pass fp32 for fp32 pixels as well")
     ap.add_argument("--model", default="xl", choices=["xl", "b", "tiny", "b_c2i", "l_c2i"])
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--image-h", type=int, default=0, help="non-square (MR) height; token grid = H/16 x W/16, rope grid = max side (sample_t2i_MR.py:73-78)")
@@ -86,7 +91,20 @@ def parse():
         a.batch, a.fp8_mfma, a.condition_type, a.adapter_size = 8, True, "hed", "base"
     if a.fp8_mfma:
         a.weights_fp8 = True
+    if a.precision == "fp32" and a.batch == 768 and a.config == 0:
+        a.batch = 384                                     # fp32 KV rows are twice as wide: 384 sequences = 162 GB
+    if a.vq_precision is None:
+        a.vq_precision = "bf16"
     return a
+
+
+def refuse_debug_environment():
+    """The library keeps a few A/B and profiling switches behind CAR_* environment variables.  Some of them change WHAT is
+    computed (CAR_DEBUG_SKIP_STEPS starts the token loop late) or how it is launched (CAR_NO_GRAPH): a number measured under any of them is
+    not the benchmark, so bench.py does not run with them set."""
+    bad = sorted(k for k in os.environ if k.startswith("CAR_"))
+    if bad:
+        raise SystemExit(f"bench.py: refusing to run with library debug / schedule switches set in the environment: {', '.join(bad)}")
 
 
 def log(msg):
@@ -180,6 +198,7 @@ def cpu_baseline(cfg, gsd, vsd, H, W, n_tok_sample):
 
 def main():
     args = parse()
+    refuse_debug_environment()
     from controlar_amd.dist import respawn_under_torchrun
     respawn_under_torchrun(__file__, sys.argv[1:], args.gpus)     # --gpus N without a torchrun environment: become N ranks
     rank = int(os.environ.get("RANK", "0"))
@@ -213,7 +232,7 @@ def main():
     gsd, vsd = synth.path_state_dicts(cfg, seed=0)          # identical on every rank (seeded CPU generator)
     # Two contexts, as the reference keeps two modules (gpt_model, vq_model).
     eng = Engine(cfg, args.precision, device=dev, weights_fp8=("mfma" if args.fp8_mfma else args.weights_fp8), kv_fp8=args.kv_fp8)
-    vq_eng = Engine(cfg, args.precision, device=dev)
+    vq_eng = Engine(cfg, args.vq_precision, device=dev)
     log("loading weights into the HIP contexts")
     eng.load_state_dict(gsd, finalize=True)
     vq_eng.load_state_dict(vsd, finalize=True)
@@ -305,6 +324,8 @@ def main():
     acc["warm"] = False
     elapsed, (toks, px) = timed_steps(dist, dev, step_and_stats, args.steps, 0, torch.cuda.synchronize)
     dec_ms, pre_ms, st = acc["dec_ms"], acc["pre_ms"], acc["st"]
+    # every token of every image went through the decode loop: the first comes from the prefill, the other n_new - 1 are one graph replay each
+    assert st["decode_steps"] == n_new - 1, f"decode loop ran {st['decode_steps']} steps, expected {n_new - 1}"
     log(f"timed region {elapsed:.2f}s")
     t_gather = 0.0
     if dist is not None:
@@ -364,6 +385,7 @@ def main():
                                     f"LlamaGen-{args.model.upper()} t2i + DINOv2-{args.adapter_size} {args.condition_type} control, {Hh}x{Ww} ({n_new} tokens), ") +
                                    f"{'fp8 (e4m3) decode weights x e4m3 activations on the fp8 MFMA, ' if args.fp8_mfma else ('fp8 (e4m3) decode weights (weight-only), ' if args.weights_fp8 else '')}"
                                    f"{'OPT-IN e4m3 KV cache (not the reference arithmetic: tolerance-graded mode), ' if args.kv_fp8 else ''}"
+                                   f"{'EXACT mode (fp32 weights / activations / KV, greedy tokens bit-identical to the fp32 reference), VQ decoder in ' + args.vq_precision + ', ' if args.precision == 'fp32' else ''}"
                                    f"cfg_scale={args.cfg_scale}, {('sampled top_k=%d top_p=%g T=%g' % (args.top_k, args.top_p, args.temperature)) if args.sample_logits else 'greedy'}, {args.batch} images/GPU/step; stages A-H "
                                    "(control encoder, generate, VQ decode) all inside the timed region",
                        "images_per_gpu": args.batch, "global_batch": G, "cfg_scale": args.cfg_scale,

@@ -64,6 +64,7 @@ SYMBOLS = {
     "car_build_id": (C.c_char_p, []),
     "car_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "car_finalize_weights": (C.c_int, [C.c_void_p]),
+    "car_check_errors": (C.c_int, [C.c_void_p]),
     "car_export_packed": (C.c_int, [C.c_void_p, C.c_char_p]),
     "car_import_packed": (C.c_int, [C.c_void_p, C.c_char_p]),
     "car_t5_configure": (C.c_int, [C.c_void_p, C.POINTER(CarT5Config)]),

@@ -44,6 +44,10 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {          // v_cvt_pk_
 
 #include "decode2_params.h"
 
+// OCP e4m3fn has no infinity: values beyond +-448 must saturate BEFORE the conversion (the oracle's kv_fp8 model and include/controlar_hip.h say
+// clamp(-448, 448); an unclamped outlier would be stored as NaN and poison every later attention step of the sequence, since P * NaN = NaN even at P = 0)
+__device__ inline float sat448(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
+
 // OCP e4m3fn bytes -> bf16 (exact: e4m3 is a subset of bf16).  lo/hi: 4 bytes each = 8 consecutive k of one row.
 // v_cvt_scalef32_pk_bf16_fp8 (gfx950): two bytes -> a packed bf16 pair in ONE instruction (scale 1.0); four per fragment where the
 // cvt_pk_f32_fp8 + shift/mask form needed sixteen — it matters in dec_attn2's e4m3-KV form, which widens every byte it streams.
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                         const int w = pos & 31, qv = w < 16 ? (w >> 2) : ((w - 16) >> 2), ev = w < 16 ? (w & 3) : (4 + ((w - 16) & 3));
                         if (p.kv8) {
                             unsigned char* vb = (unsigned char*)p.vc + sb + (long)(pos >> 5) * 2048 + (d0 >> 5) * 1024 + ((qv * 16 + (d0 & 15)) << 4) + ((d0 >> 4) & 1) * 8 + ev;
-                            const int e01 = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false), e23 = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, 0, false);
+                            const int e01 = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(x0), sat448(x1), 0, false), e23 = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(x2), sat448(x3), 0, false);
                             vb[0] = (unsigned char)(e01 & 0xff); vb[16] = (unsigned char)((e01 >> 8) & 0xff); vb[32] = (unsigned char)(e23 & 0xff); vb[48] = (unsigned char)((e23 >> 8) & 0xff);
                         } else {
                             bf16_t* vb = p.vc + sb + ((long)(pos >> 5) * 4 + (d0 >> 4)) * 512 + ((qv * 16 + (d0 & 15)) << 3) + ev;
@@ -296,8 +300,8 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                             *(uint2*)(p.qout + ((long)m * p.H + hh) * 64 + d0) = o;
                         } else if (p.kv8) {       // rotated k: bf16 round (the Linear -> RoPE rounding points), then e4m3
                             unsigned char* kb_ = (unsigned char*)p.kc + sb + (long)(pos >> 4) * 1024 + ((((d0 & 31) >> 3) * 16 + (pos & 15)) << 4) + (d0 >> 5) * 8 + (d0 & 7);
-                            int e = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(f2bf(r0)), bf2f(f2bf(r1)), 0, false);
-                            e = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(f2bf(r2)), bf2f(f2bf(r3)), e, true);
+                            int e = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(bf2f(f2bf(r0))), sat448(bf2f(f2bf(r1))), 0, false);
+                            e = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(bf2f(f2bf(r2))), sat448(bf2f(f2bf(r3))), e, true);
                             *(unsigned*)kb_ = (unsigned)e;
                         } else {
                             uint2 o; o.x = pack_bf16x2(r0, r1); o.y = pack_bf16x2(r2, r3);
@@ -617,10 +621,10 @@ __global__ void prefill_rope_kv2_kernel(bf16_t* qkv, bf16_t* kcache, bf16_t* vca
         const int d = 2 * pr;
         const int w = t & 31, qv = w < 16 ? (w >> 2) : ((w - 16) >> 2), ev = w < 16 ? (w & 3) : (4 + ((w - 16) & 3));
         if (kv8) {      // e4m3 bytes (K8 / V8 layouts); the prefill's own attention reads the bf16 rows of `qkv`, not the cache
-            const int ek = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(kr0), bf2f(kr1), 0, false);
+            const int ek = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(bf2f(kr0)), sat448(bf2f(kr1)), 0, false);
             unsigned char* kp = (unsigned char*)kcache + sb + (long)(t >> 4) * 1024 + ((((d & 31) >> 3) * 16 + (t & 15)) << 4) + (d >> 5) * 8 + (d & 7);
             kp[0] = (unsigned char)(ek & 0xff); kp[1] = (unsigned char)((ek >> 8) & 0xff);
-            const int ev2 = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(row[2 * dim + h * 64 + d]), bf2f(row[2 * dim + h * 64 + d + 1]), 0, false);
+            const int ev2 = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(bf2f(row[2 * dim + h * 64 + d])), sat448(bf2f(row[2 * dim + h * 64 + d + 1])), 0, false);
             unsigned char* vp = (unsigned char*)vcache + sb + (long)(t >> 5) * 2048 + (d >> 5) * 1024 + ((qv * 16 + (d & 15)) << 4) + ((d >> 4) & 1) * 8 + ev;
             vp[0] = (unsigned char)(ev2 & 0xff); vp[16] = (unsigned char)((ev2 >> 8) & 0xff);
         } else {

@@ -19,6 +19,7 @@
 
 // decode2.hip: parameter blocks shared through one header
 #include "decode2_params.h"
+#include "decode_f32_params.h"
 #include "kernel_params.h"
 extern "C" {
 int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st);
@@ -64,10 +65,13 @@ void car_launch_swiglu(int mode, const void* in, void* out, long rows, int hidde
 void car_launch_sample_greedy(const SampleP* p, hipStream_t st);
 void car_launch_advance(int* pos, int* step, hipStream_t st);
 void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st);
-void car_launch_dec_attn(int mode, const AttnP* p, int b, hipStream_t st);
 void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st);
 void car_launch_label_index(const int64_t* labels, const int* row_img, const int* row_unc, int num_classes, int* idx, int* err_flag, int b, hipStream_t st);
 void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, hipStream_t st);
+void car_launch_pack_frag_f32(const void* src, void* dst, long N, long K, hipStream_t st);
+int car_launch_dec_gemm_f32_cfg(const GemmFP* p, int epi, int cfg, hipStream_t st);
+int car_pick_gemm_f32_cfg(int M, int N, int K, int epi);
+void car_launch_dec_attn_f32(const AttnFP* p, int b, hipStream_t st);
 }
 
 static thread_local std::string g_create_err;
@@ -119,7 +123,9 @@ struct car_ctx {
     int dbg_skip = 0;
     int n_cu = 256;       // compute units of the device (persistent-grid sizing)
     DevBuf rowimg;       // [b] int: image index of each row
-    DevBuf rowunc, dev_flags; std::vector<int> h_rowunc;   // c2i: uncond-row marks (device + the host copy the async upload reads); sticky device error flags ([0] = class label out of range)
+    DevBuf rowunc; std::vector<int> h_rowunc;   // c2i: uncond-row marks (device + the host copy the async upload reads)
+    int* host_flags = nullptr;   // sticky error flags raised by device code, in host-mapped pinned memory ([0] = class label out of range): the kernel writes it
+                                 // with a system-scope store, and every entry that takes this context reads it without a host wait (check_sticky)
     DevBuf canny_map;    // car_canny: uint8 [B,H,W] candidate/edge map + the "changed" flag
     car_t5_config t5 = {}; bool has_t5 = false;
     DevBuf t5_in;        // int32 ids [B*T] | uint8 key mask [B*T] | staging for host-side int64 inputs
@@ -134,6 +140,16 @@ struct car_ctx {
 
 #define FAIL(ctx, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return -1; } while (0)
 #define HIPCHK(ctx, x) do { hipError_t _e = (x); if (_e != hipSuccess) FAIL(ctx, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+// Errors that only the device can detect (today: a c2i class label outside [0, num_classes] in a device-resident label tensor) cannot fail the call that
+// enqueued the work without a host wait.  They are raised as sticky flags in host-mapped memory and fail the NEXT call on the context that runs after the
+// offending kernel has executed (car_generate*, car_encode_control, car_vq_*, car_get_stats, car_check_errors) — the reference's nn.Embedding fails
+// asynchronously on a GPU as well.  The flag is cleared by the call that reports it.
+static int check_sticky(car_ctx* c) {
+    if (!c->host_flags) return 0;
+    volatile int* f = c->host_flags;
+    if (f[0]) { f[0] = 0; FAIL(c, "car_generate_c2i: an earlier call on this context received a class label outside [0, %d] (clamped to the null class on the device): its tokens are invalid", c->cfg.num_classes); }
+    return 0;
+}
 #define NEED(ctx, buf, bytes) do { if (!(buf).ensure(bytes)) FAIL(ctx, "out of device memory allocating %zu bytes (%s:%d)", (size_t)(bytes), __FILE__, __LINE__); } while (0)
 
 static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -220,7 +236,7 @@ extern "C" void car_destroy(car_ctx* c) {
     for (auto& kv : c->resize_cache) { (void)hipFree(kv.second.iy); (void)hipFree(kv.second.ix); if (kv.second.wy) (void)hipFree(kv.second.wy); if (kv.second.wx) (void)hipFree(kv.second.wx); }
     if (c->rope) (void)hipFree(c->rope);
     c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
-    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release(); c->rowunc.release(); c->dev_flags.release(); c->canny_map.release(); c->t5_in.release(); c->t5_bias.release();
+    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release(); c->rowunc.release(); if (c->host_flags) { (void)hipHostFree(c->host_flags); c->host_flags = nullptr; } c->canny_map.release(); c->t5_in.release(); c->t5_bias.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
     (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 7; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); (void)hipEventDestroy(c->ev_phase[i]); }
@@ -248,6 +264,8 @@ static int upload(car_ctx* c, const std::string& name, const std::vector<float>&
     auto it = c->w.find(name);
     if (it != c->w.end() && it->second.p) (void)hipFree(it->second.p);
     c->w[name] = t;
+    auto pk = c->w.find(name + "#pk32");       // a re-loaded tensor invalidates its exact-mode fragment image (rebuilt by car_finalize_weights)
+    if (pk != c->w.end()) { if (pk->second.p) (void)hipFree(pk->second.p); c->w.erase(pk); }
     return 0;
 }
 
@@ -621,6 +639,25 @@ extern "C" int car_finalize_weights(car_ctx* c) {
         for (auto& r : lin) if (Wp(c, r) && !Wp(c, r + sfx)) { if (nmiss < 6) missing += r + sfx + " "; ++nmiss; }
     }
     if (nmiss) FAIL(c, "car_finalize_weights: %d required tensors missing, e.g. %s", nmiss, missing.c_str());
+    if (!vq_only && c->mode == CAR_F32) {
+        // exact mode: the five decode linears also get their fp32 MFMA-fragment image (decode_f32.hip dec_gemm_f32; the row-major copy stays the
+        // prefill operand).  Built on the device from the resident row-major tensor, once.
+        std::vector<std::string> lin = {"output.weight"};
+        for (int i = 0; i < g.n_layer; ++i) {
+            const std::string p = "layers." + std::to_string(i) + ".";
+            for (const char* s : {"attention.wqkv.weight", "attention.wo.weight", "feed_forward.w13.weight", "feed_forward.w2.weight"}) lin.push_back(p + s);
+        }
+        for (auto& r : lin) {
+            const Wt& src = c->w[r];
+            if (src.shape.size() != 2 || src.shape[0] % 16 || src.shape[1] % 16) FAIL(c, "%s: exact-mode decode packing needs N%%16==0 and K%%16==0", r.c_str());
+            auto it = c->w.find(r + "#pk32");
+            if (it != c->w.end() && it->second.p && it->second.bytes == src.bytes) continue;
+            if (ensure_w(c, r + "#pk32", src.bytes, src.shape, src.numel)) return -1;
+            car_launch_pack_frag_f32(c->w[r].p, c->w[r + "#pk32"].p, src.shape[0], src.shape[1], 0);
+        }
+        hipError_t e2 = hipStreamSynchronize(0); if (e2 == hipSuccess) e2 = hipGetLastError();
+        if (e2 != hipSuccess) FAIL(c, "car_finalize_weights: fp32 fragment packing failed: %s", hipGetErrorString(e2));
+    }
     c->finalized = true;
     return 0;
 }
@@ -826,6 +863,7 @@ static void fence_out(car_ctx* c, hipStream_t caller) { (void)hipEventRecord(c->
 
 // ------------------------------------------------------------------------------------- control encoder
 extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype, int32_t B, int32_t H, int32_t W, void* out, void* stream_) {
+    if (c && check_sticky(c)) return -1;
     if (!c) return -1;
     if (!c->finalized) FAIL(c, "car_encode_control: call car_finalize_weights first");
     if (!c->has_gpt) FAIL(c, "car_encode_control: this context holds VQ weights only");
@@ -1032,14 +1070,29 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     return 0;
 }
 
+// Exact mode (decode_f32.hip): 8 kernels per layer — norm -> wqkv(+RoPE, q scale, K/V rows written at *pos) -> attention (fixed 128-position
+// splits) -> combine -> wo(+residual) -> norm -> w1|w3(+SwiGLU) -> w2(+residual); every linear runs on the exact fp32 MFMA over the fragment-packed
+// weights.  Nothing here depends on the batch except the tile shape, which does not change an output's arithmetic: a sequence decodes to the
+// same bits alone and in a batch of 384.
 static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b, int B, int S_max, int n_tok, int nsplit, bool use_ctrl,
-                               float cs, const SampleP& sp_tmpl, hipStream_t st) {
+                               float cs, const SampleP& sp_tmpl, const unsigned char* maskb, hipStream_t st) {
     const car_config& g = c->cfg; const int mode = c->mode; const size_t e = c->esz;
-    const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, li = g.n_layer / 3;
+    const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, li = g.n_layer / 3, V = g.vocab_size;
     const size_t kv_layer = (size_t)b * Hn * S_max * 64;
-    int nk = 0;
+    int nk = 0, bad = 0;
+    auto gemm = [&](const std::string& wname, const void* X, long ldx, int N, int K, int epi, GemmFP q) {
+        q.W = (const float*)Wp(c, wname + "#pk32"); q.X = (const float*)X; q.ldx = ldx; q.M = b; q.N = N; q.K = K;
+        const int cfg = car_pick_gemm_f32_cfg(b, N, K, epi);
+        const int J = cfg % 10, Mb = (b + 15) / 16;
+        q.w_nt = (Mb + J - 1) / J == 1;
+        if (!q.W || car_launch_dec_gemm_f32_cfg(&q, epi, cfg, st)) bad = cfg ? cfg : -1;
+        ++nk;
+    };
+    GemmFP z; memset(&z, 0, sizeof(z));
+    float* qbuf = (float*)sb.qkv;                                       // [b][H][64] rotated, pre-scaled q (the prefill's qkv buffer is idle during decode)
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
+        float* kc = (float*)off(c->kv.p, (size_t)(2 * l) * kv_layer, e); float* vc = (float*)off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e);
         {   // token gather (layer 0), control add (layers 0, n/3, 2n/3), attention_norm
             NormP np; memset(&np, 0, sizeof(np));
             np.h_in = sb.h; np.h_out = sb.h; np.xn = sb.xn; np.w = Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
@@ -1047,33 +1100,26 @@ static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b, int B, int
             if (use_ctrl && l % li == 0 && l / li < 3) { np.add_mode = 1; np.ctrl = c->ctrl[l / li].p; np.pos = sb.pos; np.T = g.cls_token_num; np.n_tok = n_tok; np.cs = cs; }
             car_launch_rmsnorm(mode, &np, b, st); ++nk;
         }
-        { GemmP q = gp(sb.xn, D, Wp(c, L + "attention.wqkv.weight"), D, sb.qkv, 3 * D, b, 3 * D, D); car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk; }
+        { GemmFP q = z; q.qout = qbuf; q.kc = kc; q.vc = vc; q.rope = c->rope; q.pos = sb.pos; q.H = Hn; q.S_max = S_max; q.dim = D;
+          gemm(L + "attention.wqkv.weight", sb.xn, D, 3 * D, D, FEPI_QKV, q); }
         {
-            AttnP ap; memset(&ap, 0, sizeof(ap));
-            ap.qkv = sb.qkv; ap.kcache = off(c->kv.p, (size_t)(2 * l) * kv_layer, e); ap.vcache = off(c->kv.p, (size_t)(2 * l + 1) * kv_layer, e);
-            ap.rope = c->rope; ap.pos = sb.pos; ap.emb_mask = (const unsigned char*)c->maskb.p; ap.out = sb.att; ap.part = sb.part;
-            ap.H = Hn; ap.S_max = S_max; ap.T = g.cls_token_num; ap.dim = D; ap.nsplit = nsplit;
-            car_launch_dec_attn(mode, &ap, b, st); nk += nsplit > 1 ? 2 : 1;
+            AttnFP ap; memset(&ap, 0, sizeof(ap));
+            ap.q = qbuf; ap.kc = kc; ap.vc = vc; ap.pos = sb.pos; ap.mask = maskb; ap.part = sb.part; ap.out = (float*)sb.att;
+            ap.H = Hn; ap.S_max = S_max; ap.T = g.cls_token_num; ap.dim = D; ap.nsplit_max = nsplit;
+            car_launch_dec_attn_f32(&ap, b, st); nk += 2;
         }
-        { GemmP q = gp(sb.att, D, Wp(c, L + "attention.wo.weight"), D, sb.h, D, b, D, D); q.R = sb.h; q.ldr = D; car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk; }
+        { GemmFP q = z; q.out = (float*)sb.h; q.ldo = D; q.R = (const float*)sb.h; gemm(L + "attention.wo.weight", sb.att, D, D, D, FEPI_RESID, q); }
         { NormP np; memset(&np, 0, sizeof(np)); np.h_in = sb.h; np.xn = sb.xn; np.w = Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps; car_launch_rmsnorm(mode, &np, b, st); ++nk; }
-        if (mode == CAR_BF16) {
-            GemmP q = gp(sb.xn, D, Wp(c, L + "feed_forward.w13.weight"), D, sb.mid, Fh, b, 2 * Fh, D); q.swiglu = 1; car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk;
-        } else {
-            GemmP q = gp(sb.xn, D, Wp(c, L + "feed_forward.w13.weight"), D, sb.mid2, 2 * Fh, b, 2 * Fh, D); car_launch_gemm(mode, AMODE_PLAIN, &q, st);
-            car_launch_swiglu(mode, sb.mid2, sb.mid, b, Fh, st); nk += 2;
-        }
-        { GemmP q = gp(sb.mid, Fh, Wp(c, L + "feed_forward.w2.weight"), Fh, sb.h, D, b, D, Fh); q.R = sb.h; q.ldr = D; car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk; }
+        { GemmFP q = z; q.out = (float*)sb.mid; q.ldo = Fh; gemm(L + "feed_forward.w13.weight", sb.xn, D, 2 * Fh, D, FEPI_SWIGLU, q); }
+        { GemmFP q = z; q.out = (float*)sb.h; q.ldo = D; q.R = (const float*)sb.h; gemm(L + "feed_forward.w2.weight", sb.mid, Fh, D, Fh, FEPI_RESID, q); }
     }
     { NormP np; memset(&np, 0, sizeof(np)); np.h_in = sb.h; np.xn = sb.xn; np.w = Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps; car_launch_rmsnorm(mode, &np, b, st); ++nk; }
-    {   // logits: bf16-rounded then widened (gpt_t2i.py:470) — rnd() in the epilogue, fp32 storage
-        GemmP q = gp(sb.xn, D, Wp(c, "output.weight"), D, sb.logits, g.vocab_size, b, g.vocab_size, D); q.out_f32 = 1;
-        car_launch_gemm(mode, AMODE_PLAIN, &q, st); ++nk;
-    }
+    { GemmFP q = z; q.out = sb.logits; q.ldo = V; gemm("output.weight", sb.xn, D, V, D, FEPI_PLAIN, q); }      // fp32 logits (exact mode has no bf16 round)
     car_launch_advance(sb.pos, sb.step, st); ++nk;      // pos = T+i+1 consumed next step; step indexes the token being sampled
     SampleP sp = sp_tmpl; car_launch_sample_greedy(&sp, st); ++nk;
     c->n_dec_kernels = nk;
     (void)B;
+    if (bad) FAIL(c, "exact-mode decode GEMM: tile configuration %d rejected (b=%d, dim=%d, ffn=%d, vocab=%d: N %% 32 and K %% 16 must be 0)", bad, b, D, Fh, V);
     return 0;
 }
 
@@ -1103,6 +1149,7 @@ extern "C" int car_generate_c2i(car_ctx* c, const int64_t* labels, int32_t B, in
 static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, const int64_t* labels, const int64_t* emb_mask, int32_t B, int32_t n_new,
                          int32_t use_control, const car_sampling* sp, int32_t* out_tokens, const int32_t* forced_tokens,
                          float* logits_out, void* stream_) {
+    if (check_sticky(c)) return -1;
     if (!c->finalized) FAIL(c, "car_generate: call car_finalize_weights first");
     if (!c->has_gpt) FAIL(c, "car_generate: this context holds VQ weights only");
     if (!sp || !out_tokens || B <= 0 || n_new <= 0) FAIL(c, "car_generate: bad arguments");
@@ -1162,13 +1209,12 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     NEED(c, c->ws[7], (size_t)rowsP * (mode == CAR_BF16 ? Fh : 3 * Fh) * e);  // ffn mid (+ interleaved w13 out in exact mode)
     NEED(c, c->ws[8], (size_t)rowsP * D * e);                                 // attention out
     NEED(c, c->ws[9], (size_t)b * V * 4);                                     // logits fp32
-    // exact mode: ALWAYS 16 KV splits, whatever the batch — the split count fixes the order in which a row's softmax partial sums are folded, so a
-    // sequence decodes to the same bits in a batch of 1 and in a batch of 192 (every other exact-mode kernel already sums one fixed-order fp32
-    // chain per output): tests/test_parity_gpu.py::test_exact_mode_is_batch_invariant, bench.py --precision fp32 (row 0 = the XL golden).
-    // CAR_EXACT_NSPLIT_AUTO=1 restores the batch-dependent count (A/B only).
-    const bool ns_auto = fast || getenv("CAR_EXACT_NSPLIT_AUTO") != nullptr;
-    int nsplit = ns_auto ? 1 : 16;
-    if (ns_auto) { const int wg = b * Hn; while (wg * nsplit < 1024 && nsplit < 16) nsplit *= 2; }
+    // exact mode: KV splits with boundaries fixed in ABSOLUTE positions (AF_SPLIT rows each), whatever the batch — the split layout fixes the order in
+    // which a row's softmax partial sums are folded, so a sequence decodes to the same bits in a batch of 1 and in a batch of 384 (every other
+    // exact-mode kernel sums one fixed-order fp32 chain per output): tests/test_parity_gpu.py::test_exact_mode_is_batch_invariant,
+    // bench.py --precision fp32 (row 0 = the XL golden).
+    int nsplit = fast ? 1 : (S_max + AF_SPLIT - 1) / AF_SPLIT;
+    if (fast) { const int wg = b * Hn; while (wg * nsplit < 1024 && nsplit < 16) nsplit *= 2; }
     NEED(c, c->ws[10], (size_t)b * Hn * nsplit * 66 * 4);                     // split-KV partials
     NEED(c, c->ws[11], (size_t)B * (use_control ? n_tok : 1) * D * e);        // condition_mlp output / mlp mid
     NEED(c, c->scal, (size_t)(16 + 2 * b + 2) * 4 + sizeof(SampleDyn) + 16);
@@ -1211,10 +1257,10 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         // raises a sticky device flag that car_get_stats reports (the reference's nn.Embedding fails asynchronously on a GPU as well).
         c->h_rowunc.assign(row_unc.begin(), row_unc.end());
         NEED(c, c->rowunc, (size_t)b * 4 + 16);
-        if (!c->dev_flags.p) { NEED(c, c->dev_flags, 64); HIPCHK(c, hipMemsetAsync(c->dev_flags.p, 0, 64, st)); }
+        if (!c->host_flags) { HIPCHK(c, hipHostMalloc((void**)&c->host_flags, 64, hipHostMallocMapped)); memset(c->host_flags, 0, 64); }
         HIPCHK(c, hipMemcpyAsync(c->rowunc.p, c->h_rowunc.data(), (size_t)b * 4, hipMemcpyHostToDevice, st));
         int* didx = cur;       // cur_tok[b] is free until the prefill sampler writes it
-        car_launch_label_index(labels, (const int*)c->rowimg.p, (const int*)c->rowunc.p, g.num_classes, didx, (int*)c->dev_flags.p, b, st);
+        car_launch_label_index(labels, (const int*)c->rowimg.p, (const int*)c->rowunc.p, g.num_classes, didx, c->host_flags, b, st);
         car_launch_gather_rows(mode, Wp(c, "cls_embedding.embedding_table.weight"), didx, h, b, D, st);
     } else {
         const long per = (long)T * g.caption_dim; const size_t ib = text_dtype == CAR_DT_BF16 ? 2 : 4;
@@ -1367,7 +1413,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     bool capturing = false;
     int step_rc = 0;
     auto enqueue_steps = [&](int k) {      // k consecutive decode steps of every chain
-        if (!fast) { for (int s = 0; s < k; ++s) enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, st); return; }
+        if (!fast) { for (int s = 0; s < k; ++s) step_rc |= enqueue_decode_step(c, sb, b, B, S_max, n_tok, nsplit, use_control != 0, cs, spp, fmask, st); return; }
         if (NG >= 2 && capturing) {         // the chains are parallel branches of the captured graph
             if (!phase) {
                 (void)hipEventRecord(c->ev_fork, st);
@@ -1467,6 +1513,14 @@ extern "C" int car_sample_logits(car_ctx* c, const float* logits, int32_t B, int
     return 0;
 }
 
+// Waits for everything enqueued on the context's stream, then reports (and clears) sticky device-side errors — the way to learn NOW whether the
+// tokens of the last car_generate_c2i call are valid (include/controlar_hip.h).
+extern "C" int car_check_errors(car_ctx* c) {
+    if (!c) return -1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_sticky(c);
+}
+
 extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
     if (!c || !out) return -1;
     float ms = 0.f;
@@ -1485,12 +1539,7 @@ extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
         c->stats.decode_algo_bytes = (int64_t)(c->st_wbytes * c->st_nsteps + kvb);
     }
     *out = c->stats;
-    if (c->dev_flags.p) {        // sticky device-side error flags (this entry synchronises anyway)
-        int f[2] = {0, 0};
-        (void)hipStreamSynchronize(c->stream);
-        if (hipMemcpy(f, c->dev_flags.p, 8, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
-        if (f[0]) { (void)hipMemset(c->dev_flags.p, 0, 64); FAIL(c, "car_generate_c2i: a class label outside [0, %d] was passed (clamped to the null class on the device)", c->cfg.num_classes); }
-    }
+    if (check_sticky(c)) return -1;        // sticky device-side error flags (this entry has just synchronised: everything enqueued so far has reported)
     return 0;
 }
 
@@ -1744,6 +1793,7 @@ struct VqOps {
 
 // VQModel.encode (vq_model.py:41-46) -> min_encoding_indices: img fp32 NCHW [B,3,H,W] (H, W multiples of 16) -> tokens int32 [B, (H/16)(W/16)]
 extern "C" int car_vq_encode(car_ctx* c, const float* img, int32_t B, int32_t H, int32_t W, int32_t* out_tokens, void* stream_) {
+    if (c && check_sticky(c)) return -1;
     if (!c) return -1;
     if (!c->finalized) FAIL(c, "car_vq_encode: call car_finalize_weights first");
     if (!Wp(c, "encoder.conv_in.weight") || !Wp(c, "quantize.embedding.weight")) FAIL(c, "car_vq_encode: VQ encoder weights were not loaded into this context");
@@ -1785,6 +1835,7 @@ extern "C" int car_vq_encode(car_ctx* c, const float* img, int32_t B, int32_t H,
 
 // ------------------------------------------------------------------------------------- VQ decode
 extern "C" int car_vq_decode(car_ctx* c, const int32_t* tokens, int32_t B, int32_t hh, int32_t ww, float* out_nchw, void* stream_) {
+    if (c && check_sticky(c)) return -1;
     if (!c) return -1;
     if (!c->finalized) FAIL(c, "car_vq_decode: call car_finalize_weights first");
     if (!Wp(c, "quantize.embedding.weight")) FAIL(c, "car_vq_decode: VQ weights were not loaded into this context");

@@ -718,6 +718,90 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
         }
 }
 
+// fp32 on the matrix cores: the same contract as gemm_f32_kernel (K % 16 == 0, K-contiguous operands, every AMODE, the generic epilogue) on
+// v_mfma_f32_16x16x4_f32 — exact fp32 products and sums (an fmaf chain per instruction), 16 x the VALU kernel's arithmetic rate per CU.
+// 128 x 128 tile, 4 waves of 64 x 64 (4 x 4 accumulator fragments), K step 16 through a double-buffered LDS stage (row stride 20 floats);
+// one 16-byte LDS read per lane feeds four MFMAs: lane (r, q) holds k = 16kt + 4q .. 4q+3 of row r and step s multiplies component s of both
+// operands (a fixed permutation of K inside each 16-block, the same for A and W — the order decode_f32.hip uses).  Every output element sums the
+// k-blocks in order, whatever M: a row's result does not depend on the batch it is computed in.
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+#define F32_LD 20
+template <int AMODE>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) float sA[2][128 * F32_LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][128 * F32_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z, z0 = z / p.nb1, z1 = z - z0 * p.nb1;
+    const float* A = (const float*)p.A + z0 * p.sA0 + z1 * p.sA1;
+    const float* W = (const float*)p.W + z0 * p.sW0 + z1 * p.sW1;
+    const long zC = z0 * p.sC0 + z1 * p.sC1, zR = z0 * p.sR0 + z1 * p.sR1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int lrow = tid >> 1, lkc = (tid & 1) * 8;               // loader: one row, two 16-byte chunks of the 16-wide k step
+    const Geo geo = { p.M, p.Cin, p.Ho, p.Wo, p.ups, p.lda, p.patch };
+    const ARow ar = make_arow<AMODE>(geo, m0 + lrow);
+    const bool wok = (n0 + lrow) < p.N;
+    const float* wp = W + (long)(n0 + lrow) * p.ldw + lkc;
+    float4 ra[2], rb[2];
+    const float4 zero4 = make_float4(0, 0, 0, 0);
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const long o = a_off<AMODE>(geo, ar, kt * 16 + lkc + c * 4);
+            ra[c] = zero4; rb[c] = zero4;
+            if (o >= 0) ra[c] = *(const float4*)(A + o);
+            if (wok) rb[c] = *(const float4*)(wp + (long)kt * 16 + c * 4);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { *(float4*)&sA[buf][lrow * F32_LD + lkc + c * 4] = ra[c]; *(float4*)&sB[buf][lrow * F32_LD + lkc + c * 4] = rb[c]; }
+    };
+    f4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
+    const int nk = p.K / 16;
+    gload(0); sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        f4_t xa[4], wa[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[j] = *(const f4_t*)&sA[buf][(wm * 64 + j * 16 + c16) * F32_LD + q4 * 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wa[i] = *(const f4_t*)&sB[buf][(wn * 64 + i * 16 + c16) * F32_LD + q4 * 4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i][s], xa[j][s], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    const float* bias = (const float*)p.bias; const float* scale = (const float*)p.scale; const float* R = (const float*)p.R;
+    const bool vec = (p.ldc & 3) == 0 && ((zC & 3) == 0) && (((uintptr_t)p.C & 15) == 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + c16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + q4 * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (n + r < p.N) ? epi_value<float>(p, bias, scale, R, zR, m, (long)m, n + r, acc[i][j][r]) : 0.f;
+            float* dst = (float*)p.C + zC + (long)m * p.ldc + n;
+            if (vec && n + 3 < p.N) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            else { for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = v[r]; }
+        }
+    }
+}
+
 // host launchers -------------------------------------------------------------------------
 // Will car_launch_gemm(mode, AMODE_CONV3, p) take conv3_halo64_kernel — the kernel whose epilogue can also write the GroupNorm stage-1 partials of its
 // output (GemmP::gn_part)?  engine.hip asks before it lets the next GroupNorm skip its read-only pass.
@@ -800,6 +884,16 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
     } else {
         if (p.gn_part) { fprintf(stderr, "car_launch_gemm: GemmP::gn_part is a bf16 conv3_halo64_kernel feature\n"); abort(); }
         p.patch = 0;                              // the exact-mode kernel enumerates pixels linearly
+        // exact mode: fp32 MFMA tiles (16 x the VALU rate per CU); the round-1 VALU kernel serves the shapes whose strides break the loader's 16-byte chunks
+        const bool mfma_ok = p.K % 16 == 0 && p.ldw % 4 == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && p.sA0 % 4 == 0 && p.sA1 % 4 == 0 && p.sW0 % 4 == 0 && p.sW1 % 4 == 0 &&
+                             (amode == AMODE_PLAIN ? p.lda % 4 == 0 : p.Cin % 4 == 0);
+        if (mfma_ok) {
+            dim3 g((p.N + 127) / 128, (p.M + 127) / 128, p.nb0 * p.nb1);
+            if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_f32_mfma_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);
+            else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_f32_mfma_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(gemm_f32_mfma_kernel<AMODE_CONV3>, g, dim3(256), 0, st, p);
+            return;
+        }
         dim3 g((p.N + 63) / 64, (p.M + 63) / 64, p.nb0 * p.nb1);
         if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_f32_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);
         else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_f32_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);

@@ -1,4 +1,4 @@
-// kernel_params.h — parameter blocks of the kernels in ops.hip / decode.hip / attn.hip, shared with their caller (engine.hip): ONE definition each
+// kernel_params.h — parameter blocks of the kernels in ops.hip / attn.hip, shared with their caller (engine.hip): ONE definition each
 // (engine.hip used to keep hand-synchronised copies).  decode2.hip's blocks live in decode2_params.h.
 #pragma once
 #include "car_common.h"
@@ -30,18 +30,6 @@ struct SampleP {
     int logits_ks; long logits_stride; int round_bf16;   // logits given as split-K partials [ks][b][V]; bf16 rounding of the sum (gpt_t2i.py:470)
     int stochastic; float temperature; int top_k; float top_p; unsigned long long seed; int row0;   // sample_logits=True path (generate.py:59-74)
     const struct SampleDyn* dyn;    // when set, (seed, temperature, top_k, top_p) are read from device memory: a captured graph stays valid across calls
-};
-
-struct AttnP {
-    const void* qkv;        // [b, 3*dim] T, raw wqkv output (q | k | v)
-    void* kcache; void* vcache;   // [b, H, S_max, 64] T (this layer)
-    const float* rope;      // [n_pos, 32, 2] fp32 (cos, sin); rows < T are zero (gpt_t2i.py:518)
-    const int* pos;         // device scalar: input_pos p
-    const unsigned char* emb_mask;  // [b, T] (text-pad mask, already duplicated for the CFG half) or null
-    void* out;              // [b, dim] T                        (nsplit == 1)
-    float* part;            // [b, H, nsplit, 66] fp32 (m, l, o[64]) (nsplit > 1)
-    int H, S_max, T, dim, nsplit;
-    const float* qkv_parts; int qkv_ks; long qkv_stride;   // fast path: wqkv output as fp32 split-K partials [ks][b][3*dim]
 };
 
 struct FlashP {

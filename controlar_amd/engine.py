@@ -245,6 +245,11 @@ class Engine:
                                            C.c_void_p(out.data_ptr()), C.c_void_p(_stream_ptr())), "car_t5_encode")
         return out
 
+    def check_errors(self):
+        """Waits for the work enqueued on this context and raises if device code reported an error no entry could fail on synchronously
+        (today: a c2i class label outside [0, num_classes] in a device-resident label tensor — include/controlar_hip.h, car_generate_c2i)."""
+        self._check(self.lib.car_check_errors(self._h), "car_check_errors")
+
     def stats(self) -> dict:
         s = L.CarStats()
         self._check(self.lib.car_get_stats(self._h, C.byref(s)), "car_get_stats")

@@ -192,6 +192,11 @@ int car_t5_encode(car_ctx* ctx, const int64_t* input_ids, const int64_t* attenti
  * does not exist on this path.  NOTE: in the reference snapshot this branch only runs with cfg_scale <= 1
  * (generate.py:88 passes control_strength, which gpt.py's forward does not accept); cfg_scale > 1 is
  * accepted here with the semantics generate.py:140-146 spells out (null class = num_classes).
+ * Label range: labels live on the device and the entry never waits for the host, so a label outside [0, num_classes] cannot fail THIS call.
+ * The device clamps it to the null class and raises a sticky error flag (host-mapped memory); the flag fails — with car_last_error naming this
+ * entry — the next call on the context that runs after the offending kernel has executed: car_generate*, car_encode_control, car_vq_decode /
+ * car_vq_encode, car_get_stats, or car_check_errors (which waits for the context's stream first: call it to validate the tokens right away).
+ * The reporting call clears the flag.  (The reference's nn.Embedding fails asynchronously on a GPU as well.)
  */
 int car_generate_c2i(car_ctx* ctx, const int64_t* labels, int32_t B, int32_t n_new, int32_t use_control, const car_sampling* sp,
                      int32_t* out_tokens, const int32_t* forced_tokens, float* logits_out, void* stream);
@@ -229,6 +234,9 @@ typedef struct car_stats {
     int32_t reserved[6];
 } car_stats;
 int car_get_stats(car_ctx* ctx, car_stats* out);
+
+/* Waits for the work enqueued on the context, then reports (non-zero + car_last_error) and clears sticky device-side errors — see car_generate_c2i. */
+int car_check_errors(car_ctx* ctx);
 
 /* Host-only: the MFMA-fragment image of a decode linear W[N,K] (bf16 bits): chunk (rb,kb) = 64 lanes x 8 values, lane l holds
  * W[16rb + (l&15)][32kb + 8(l>>4) .. +8]; chunks ordered [rb][kb].  N % 16 == 0, K % 32 == 0. */

@@ -230,6 +230,13 @@ CASES = {
     # BASELINE config 2 at full size (GPT-XL, 512x512, 1024 tokens), B=1; ~2-4 min of CPU
     "xl_canny_512_cfg1": lambda: run_case("xl_canny_512_cfg1", C.xl_t2i(1024, "small", "canny"), 1, 512, 512, 1.0,
                                           vq=False, keep_logits=64),
+    # BASELINE config 2 with the reference's default guidance (sample_t2i.py:207: cfg_scale 4; 2B = 2 rows per step), GPT-XL, 512x512, B=1; ~5 min of CPU
+    "xl_canny_512_cfg4": lambda: run_case("xl_canny_512_cfg4", C.xl_t2i(1024, "small", "canny"), 1, 512, 512, 4.0,
+                                          vq=False, keep_logits=64),
+    # BASELINE config 4 at full size AND full width (sample_t2i_MR.py:73-78,182-185: GPT-XL, 768x512 -> 48 x 32 = 1536 tokens on a rope grid of 48,
+    # block_size 2304, S_max 1656, DINOv2-small at 672x448), cfg 4; ~10 min of CPU
+    "xl_mr_768x512_cfg4": lambda: run_case("xl_mr_768x512_cfg4", C.xl_t2i(2304, "small", "canny"), 1, 768, 512, 4.0,
+                                           vq=False, keep_logits=64),
 }
 DEFAULT = ["tiny_canny_cfg1", "tiny_depth_cfg4", "tiny_mr_192x128", "tiny_mr_128x192", "tiny_cfg_interval",
            "tiny_canny_cfg1_bf16", "vq16_real_8x8"]

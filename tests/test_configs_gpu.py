@@ -301,3 +301,32 @@ def test_e4m3_kv_cache_opt_in(size):
     # the mode exists only in the fast mode
     with pytest.raises(RuntimeError):
         Engine(cfg, "fp32", kv_fp8=True)
+
+
+def test_e4m3_kv_cache_saturates_outliers():
+    """OCP e4m3fn has no infinity: a K / V element beyond +-448 must be stored as +-448 (include/controlar_hip.h and the oracle's kv_fp8 model say
+    clamp), never as NaN — one NaN row would poison every later step of the sequence (P * NaN = NaN even at P = 0).  One V channel and one K channel of
+    layer 0 are scaled so that most of their cached values exceed 448; the logits must stay finite and follow the oracle running the same clamping model."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    from oracle import controlar_oracle as O
+    _threads()
+    cfg = C.tiny_t2i(64, "canny"); B, H, W, n_new = 2, 128, 128, 24
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    gsd = {k: v.clone() for k, v in gsd.items()}
+    D = cfg.gpt.dim
+    w = gsd["layers.0.attention.wqkv.weight"]
+    w[2 * D + 5] *= 4000.0            # V, head 0, dim 5
+    w[D + 64 + 7] *= 4000.0           # K, head 1, dim 7 (rotated with its partner dim 6: both can exceed 448)
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    toks_o, logits_m = O.generate(gsd, cfg, emb, n_new, mask, cfg_scale=1.0, condition=img, return_logits=True, kv_fp8=True)
+    eng = Engine(cfg, "bf16", kv_fp8=True); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    _, logits = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=1.0, forced_tokens=toks_o, return_logits=True)
+    lg = logits.cpu()
+    assert torch.isfinite(lg).all(), "an e4m3 KV outlier was stored as NaN"
+    d = (lg - logits_m).abs()
+    _record("kv_e4m3_outliers[tiny]", hip_vs_model_max=float(d.max()), hip_vs_model_mean=float(d.mean()))
+    assert float(d.mean()) <= 0.25 and float(d.max()) <= 2.5, (float(d.max()), float(d.mean()))
+    eng.close()

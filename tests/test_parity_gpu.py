@@ -343,6 +343,16 @@ def test_c2i_label_errors_without_host_round_trip():
     null = eng.generate(torch.tensor([1, cfg.gpt.num_classes, 0]).cuda(), 8, None, cfg_scale=1.0).cpu()
     assert torch.equal(t, null)                                          # the offending row was decoded with the null class
     eng.stats()                                                          # the flag is sticky once, then cleared
+    # the flag lives in host-mapped memory: a caller that never asks for stats() still gets the failure — on the generate path itself (the next
+    # call on the context after the offending kernel ran) or at once through check_errors()
+    eng.generate(bad, 8, None, cfg_scale=1.0).cpu()                      # .cpu() waits for the caller's stream: the label kernel has run
+    with pytest.raises(RuntimeError, match="class label outside"):
+        eng.generate(labels.cuda(), 8, None, cfg_scale=1.0)
+    eng.generate(labels.cuda(), 8, None, cfg_scale=1.0)                  # reported once, cleared
+    eng.generate(bad, 8, None, cfg_scale=1.0)
+    with pytest.raises(RuntimeError, match="class label outside"):
+        eng.check_errors()                                               # waits for the context's stream, then reports
+    eng.check_errors()
     eng.close()
 
 
