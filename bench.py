@@ -360,9 +360,13 @@ def main():
     # passes, gfx950 corrections of MI355X_MICROARCH.md §HBM applied there); any other configuration reports null.
     def measured_traffic():
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_decode_step.json")))
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_decode_step.json" if args.precision == "bf16" else "pmc_decode_step_fp32.json")))
         except Exception:
             return None, "no PMC summary for this configuration"
+        # the summary is only quoted for the library build it was measured on (tools/pmc_decode.py records car_build_id): after any kernel change the
+        # line says null until tools/profile_round.sh has been re-run
+        if rec.get("build_id") != eng.lib.car_build_id().decode():
+            return None, f"the committed PMC summary was measured on library build {str(rec.get('build_id'))[:12]}, this is {eng.lib.car_build_id().decode()[:12]}: not quoted"
         same = (not args.kv_fp8 and rec.get("model") == args.model and rec.get("batch") == args.batch and abs(rec.get("cfg_scale", 1.0) - args.cfg_scale) < 1e-6
                 and rec.get("precision") == args.precision and bool(rec.get("weights_fp8")) == bool(args.weights_fp8)
                 and rec.get("image_hw") == [Hh, Ww] and rec.get("adapter_size") == args.adapter_size)

@@ -44,6 +44,13 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {          // v_cvt_pk_
 
 #include "decode2_params.h"
 
+#ifdef CAR_STAMP
+#define STAMP(p, i) do { if (threadIdx.x == 0 && (p).stamp) { const int wg_ = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
+    if (wg_ < 2048) (p).stamp[((long)(p).stamp_slot * 2048 + wg_) * 8 + (i)] = (long long)wall_clock64(); } } while (0)
+#else
+#define STAMP(p, i) do { } while (0)
+#endif
+
 // OCP e4m3fn has no infinity: values beyond +-448 must saturate BEFORE the conversion (the oracle's kv_fp8 model and include/controlar_hip.h say
 // clamp(-448, 448); an unclamped outlier would be stored as NaN and poison every later attention step of the sequence, since P * NaN = NaN even at P = 0)
 __device__ inline float sat448(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
@@ -81,15 +88,16 @@ __device__ inline long bf16x8_to_fp8x8_(const u32x4 x) {
 template <int I, int J, int WAVES, int EPI, int F8, int NORM>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     extern __shared__ __attribute__((aligned(16))) float red_all[];   // [NORM: 16 x (K+8) bf16] then [WAVES][I*J][64] f32x4
-    static_assert(!NORM || J == 1, "the fused-norm variant serves one m-block");
+    static_assert(NORM != 1 || J == 1, "the prologue-norm variant serves one m-block");
     const int xs_ld = p.K + 8;                                         // bf16 elements per LDS row: 16-byte reads of 16 rows hit 16 distinct bank groups
     bf16_t* xs = (bf16_t*)red_all;
-    float* red = NORM ? red_all + (16 * xs_ld) / 2 : red_all;
+    float* red = NORM == 1 ? red_all + (16 * xs_ld) / 2 : red_all;
     constexpr int XPU = F8 ? 2 : 1;                                    // X chunks (k-blocks) per weight load unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // raised wave priority: when this kernel shares a CU with the other decode chain's attention waves (HBM-bound, thousands of them),
     // the instruction arbiter serves these few latency-bound waves first
     if (p.w_nt & 2) __builtin_amdgcn_s_setprio(3);
+    STAMP(p, 0);
     const int nkb = p.K >> 5, nku = nkb / XPU, Mb = (p.M + 15) >> 4;
     const int MT = (Mb + J - 1) / J;
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of tiles —
@@ -111,26 +119,51 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     const u32x4 zw = (u32x4){0u, 0u, 0u, 0u};
     // DEPTH load stages stay in flight per wave (a tile's K slice is short: the kernel is bound by how many bytes a CU
     // keeps outstanding, not by MFMA issue): ~28 KiB-chunks of operands per wave, within the register budget
+    // (round 4 tried 14 / 9 stages for the narrow tiles — w2 at K = 3584 leaves 14 k-blocks to each of 8 waves: the main loop's 2.3 us moved into the issue
+    //  phase and the kernel stayed at 5.6 us: 80 workgroups x 115 KB is bound by what one CU pulls, ~60 GB/s; profiles/r04_lat_probe_v2_rows2.txt)
     constexpr int DEPTH = (28 / (I + J * XPU)) < 2 ? 2 : ((28 / (I + J * XPU)) > 6 ? 6 : (28 / (I + J * XPU)));
-    u32x4 wr[DEPTH][I], xr[DEPTH][J * XPU];
-    auto load = [&](u32x4 (&w)[I], u32x4 (&x)[J * XPU], int ku) {
+    u32x4 wr[DEPTH][I], xr[DEPTH][J * XPU], nr[DEPTH][NORM == 2 ? XPU : 1];
+    // NORM == 2: X fragments are bf16 h rows read in place (row-major, ld = K: lane (c16, q4) takes 16 bytes of row m at k = 32 kb + 8 q4), normalised in registers
+    const bf16_t* hrow[J]; bool hok[J]; float rstd[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { const int m = (mb0 + j) * 16 + (lane & 15); hok[j] = NORM == 2 && m < p.M; hrow[j] = NORM == 2 ? p.nh_in + (long)(hok[j] ? m : 0) * p.K + (lane >> 4) * 8 : nullptr; rstd[j] = 0.f; }
+    auto load = [&](u32x4 (&w)[I], u32x4 (&x)[J * XPU], u32x4 (&nwf)[NORM == 2 ? XPU : 1], int ku) {
 #pragma unroll
         for (int i = 0; i < I; ++i) {
             const u32x4* a = wp + ((long)i * nku + ku) * 64;
             w[i] = (p.w_nt & 1) ? __builtin_nontemporal_load(a) : *a;
         }
-        if (!NORM) {
+        if (NORM == 0) {
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
                 for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (j < jn) x[j * XPU + u] = xp[((long)j * nkb + ku * XPU + u) * 64]; }
+        } else if (NORM == 2) {
+#pragma unroll
+            for (int u = 0; u < XPU; ++u) nwf[u] = *(const u32x4*)(p.nw + (ku * XPU + u) * 32 + (lane >> 4) * 8);
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (hok[j]) x[j * XPU + u] = *(const u32x4*)(hrow[j] + (ku * XPU + u) * 32); }
         }
     };
-    const bf16_t* xl = xs + (lane & 15) * xs_ld + (lane >> 4) * 8;     // NORM: this lane's row / k offset inside a k-block
-    auto compute = [&](const u32x4 (&w)[I], u32x4 (&x)[J * XPU], int ku) {
-        if (NORM) {
+    const bf16_t* xl = xs + (lane & 15) * xs_ld + (lane >> 4) * 8;     // NORM == 1: this lane's row / k offset inside a k-block
+    auto compute = [&](const u32x4 (&w)[I], u32x4 (&x)[J * XPU], const u32x4 (&nwf)[NORM == 2 ? XPU : 1], int ku) {
+        if (NORM == 1) {
 #pragma unroll
             for (int u = 0; u < XPU; ++u) x[u] = *(const u32x4*)(xl + (ku * XPU + u) * 32);
+        } else if (NORM == 2) {
+            // x = rnd(rnd(h * rstd) * w) — the rounding points of rmsnorm2_kernel (gpt_t2i.py:193-198), two bf16 per dword
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int u = 0; u < XPU; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned hv = x[j * XPU + u][e], wv = nwf[u][e];
+                        const unsigned t = pack_bf16x2(__uint_as_float(hv << 16) * rstd[j], __uint_as_float(hv & 0xffff0000u) * rstd[j]);
+                        x[j * XPU + u][e] = pack_bf16x2(__uint_as_float(t << 16) * __uint_as_float(wv << 16), __uint_as_float(t & 0xffff0000u) * __uint_as_float(wv & 0xffff0000u));
+                    }
         }
         long x8[J][2];
         if (F8 == 2) {
@@ -161,24 +194,78 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
         }
     };
     const int nkw = ku_hi - ku_lo;
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) if (d < nkw) load(wr[d], xr[d], ku_lo + d);
-    if (NORM) {
-        // ---- prologue: one wave per row (the code of rmsnorm2_kernel), rows >= M are never stored downstream
+    // NORM prologue, part 1: the loads of this wave's FIRST row (residual row, control token, norm weight) go out BEFORE the weight stream.  A wave's loads
+    // return in order: queued behind DEPTH stages of weights the norm waited for the whole burst, and fetched the norm weight only after the reduction —
+    // the prologue measured 5.2-6.6 us of an 8 us kernel (experiments/lat_probe, profiles/r04_lat_probe_before_rows2.txt); issued first, it costs one L2 round trip.
+    uint2 nh[8], na[8], nwv[8];
+    bool n_add = false;
+    if (NORM == 1) {
         const int D = p.K, ng = D >> 2;
-        for (int m = wave; m < p.M; m += WAVES) {
+        if (wave < p.M) {
+            const int m = wave;
             const bf16_t* src = p.nidx ? p.nemb + (long)p.nidx[m] * D : p.nh_in + (long)m * D;
             const bf16_t* add = p.nadd ? p.nctrl + ((long)m * p.n_tok + (*p.pos - p.nT + 1)) * D : nullptr;
+            n_add = add != nullptr;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int gi = lane + q * 64;
+                if (gi < ng) { nh[q] = *(const uint2*)(src + gi * 4); nwv[q] = *(const uint2*)(p.nw + gi * 4); if (add) na[q] = *(const uint2*)(add + gi * 4); }
+            }
+        }
+    }
+    // NORM == 2: rstd of this lane's rows from the producer's per-tile sums of squares, folded in a fixed order.  The four lanes (c16, q4 = 0..3) of a row share
+    // the work: lane q4 takes the 16-byte chunks q4, q4 + 4, ... of the row's partials (at most 8 loads, all requested at once — a scalar loop over the 40-80
+    // partials was 80 dependent L2 round trips: 7.7 us at 2 rows, 38-75 us at 64), sums them in chunk order, and the four lane sums fold through two shuffles:
+    // (s0 + s1) + (s2 + s3), the same bits in every lane.  A wave's loads return in order, so these go out BEFORE the operand stages (behind them they waited
+    // for the whole weight burst: 2.5-3.5 us); narrow tiles (J <= 2) keep them in registers across the stage issue, wide tiles finish them first.
+    float4 sv[(NORM == 2 && J <= 2) ? J : 1][8];
+    auto ssq_issue = [&](float4 (&v)[8], int j) {
+        const int np4 = p.ssq_np >> 2, q4n = lane >> 4;
+        const float4* sp = (const float4*)(p.ssq_in + (long)((mb0 + j) * 16 + (lane & 15)) * p.ssq_np);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { v[t] = make_float4(0.f, 0.f, 0.f, 0.f); if (hok[j] && q4n + 4 * t < np4) v[t] = sp[q4n + 4 * t]; }
+    };
+    auto ssq_finish = [&](const float4 (&v)[8], int j) {
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { sum += v[t].x; sum += v[t].y; sum += v[t].z; sum += v[t].w; }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        rstd[j] = hok[j] ? rsqrtf(sum / p.K + p.neps) : 0.f;
+    };
+    if (NORM == 2) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) { if (J <= 2) ssq_issue(sv[j], j); else { ssq_issue(sv[0], j); ssq_finish(sv[0], j); } }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) if (d < nkw) load(wr[d], xr[d], nr[d], ku_lo + d);
+    if (NORM == 2 && J <= 2) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) ssq_finish(sv[J <= 2 ? j : 0], j);
+    }
+    if (NORM == 1) {
+        // ---- prologue, part 2: one wave per row (the arithmetic of rmsnorm2_kernel), rows >= M are never stored downstream
+        const int D = p.K, ng = D >> 2;
+        for (int m = wave; m < p.M; m += WAVES) {
+            if (m != wave) {      // further rows of this wave (M > WAVES): loaded here, behind the weight stages already in flight
+                const bf16_t* src = p.nidx ? p.nemb + (long)p.nidx[m] * D : p.nh_in + (long)m * D;
+                const bf16_t* add = p.nadd ? p.nctrl + ((long)m * p.n_tok + (*p.pos - p.nT + 1)) * D : nullptr;
+                n_add = add != nullptr;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int gi = lane + q * 64;
+                    if (gi < ng) { nh[q] = *(const uint2*)(src + gi * 4); if (add) na[q] = *(const uint2*)(add + gi * 4); }
+                }
+            }
             float val[8][4];
             float ss = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int gi = lane + q * 64;
                 if (gi < ng) {
-                    const uint2 u = *(const uint2*)(src + gi * 4);
+                    const uint2 u = nh[q];
                     float v[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
-                    if (add) {
-                        const uint2 a = *(const uint2*)(add + gi * 4);
+                    if (n_add) {
+                        const uint2 a = na[q];
                         const float c[4] = {__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e] + bf2f(f2bf(p.ncs * c[e]))));
@@ -194,7 +281,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                 if (gi < ng) {
                     const int k = gi * 4;
                     if (p.nh_out && blockIdx.x == 0) { uint2 u; u.x = pack_bf16x2(val[q][0], val[q][1]); u.y = pack_bf16x2(val[q][2], val[q][3]); *(uint2*)(p.nh_out + (long)m * D + k) = u; }
-                    const uint2 wu = *(const uint2*)(p.nw + k);
+                    const uint2 wu = nwv[q];
                     const float w[4] = {__uint_as_float(wu.x << 16), __uint_as_float(wu.x & 0xffff0000u), __uint_as_float(wu.y << 16), __uint_as_float(wu.y & 0xffff0000u)};
                     uint2 u;
                     u.x = pack_bf16x2(bf2f(f2bf(val[q][0] * rstd)) * w[0], bf2f(f2bf(val[q][1] * rstd)) * w[1]);
@@ -205,22 +292,30 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
         }
         __syncthreads();
     }
+    STAMP(p, 1);
     for (int base = 0; base < nkw; base += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             if (base + d < nkw) {                                     // wave-uniform
-                compute(wr[d], xr[d], ku_lo + base + d);
-                if (base + d + DEPTH < nkw) load(wr[d], xr[d], ku_lo + base + d + DEPTH);
+                compute(wr[d], xr[d], nr[d], ku_lo + base + d);
+#ifdef CAR_STAMP
+                if (base + d == 0) { asm volatile("s_nop 0" ::"v"(acc[0][0][0])); STAMP(p, 2); }
+#endif
+                if (base + d + DEPTH < nkw) load(wr[d], xr[d], nr[d], ku_lo + base + d + DEPTH);
             }
         }
     }
     // ---- fold the WAVES K-slices in fixed order through LDS
     f32x4* rv = (f32x4*)red;
+#ifdef CAR_STAMP
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0])); STAMP(p, 3);
+#endif
 #pragma unroll
     for (int i = 0; i < I; ++i)
 #pragma unroll
         for (int j = 0; j < J; ++j) rv[((wave * I + i) * J + j) * 64 + lane] = acc[i][j];
     __syncthreads();
+    STAMP(p, 4);
     auto fold = [&](int i, int j) -> f32x4 {
         f32x4 s = rv[((0 * I + i) * J + j) * 64 + lane];
         for (int w = 1; w < WAVES; ++w) { const f32x4 v = rv[((w * I + i) * J + j) * 64 + lane]; s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
@@ -257,6 +352,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
             uint2 o; o.x = pack_bf16x2(s[0], s[1]); o.y = pack_bf16x2(s[2], s[3]);
             *(uint2*)(p.outp + off) = o;
         } else {
+            float ssq_acc = 0.f;
 #pragma unroll
             for (int ii = 0; ii < IW; ++ii) {
                 const int n0 = (rb0 + ip * IW + ii) * 16 + q4 * 4;
@@ -273,6 +369,10 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                     o.x = pack_bf16x2(h0 + bf2f(f2bf(a[0])), h1 + bf2f(f2bf(a[1])));
                     o.y = pack_bf16x2(h2 + bf2f(f2bf(a[2])), h3 + bf2f(f2bf(a[3])));
                     *(uint2*)hp = o;
+                    if (p.ssq_out) {       // the squares of the STORED residual values: the next RMSNorm's row sum, one partial per (row, pair of row-blocks)
+                        const float s0 = __uint_as_float(o.x << 16), s1 = __uint_as_float(o.x & 0xffff0000u), s2 = __uint_as_float(o.y << 16), s3 = __uint_as_float(o.y & 0xffff0000u);
+                        ssq_acc += s0 * s0; ssq_acc += s1 * s1; ssq_acc += s2 * s2; ssq_acc += s3 * s3;
+                    }
                 } else {   // EPI_QKV
                     const int pos = *p.pos;
                     const int sec = n0 / p.dim, within = n0 - sec * p.dim, hh = within >> 6, d0 = within & 63;
@@ -311,15 +411,22 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                     }
                 }
             }
+            if (EPI == EPI_RESID && p.ssq_out) {       // lanes (c16, q4 = 0..3) hold the 4-column pieces of row m: fold them in a fixed order, one store per row
+                ssq_acc += __shfl_xor(ssq_acc, 16, 64); ssq_acc += __shfl_xor(ssq_acc, 32, 64);
+                if (q4 == 0) p.ssq_out[(long)m * p.ssq_ld + (rb0 / IW + ip)] = ssq_acc;
+            }
         }
     }
+#ifdef CAR_STAMP
+    __builtin_amdgcn_s_waitcnt(0); STAMP(p, 5);
+#endif
 }
 
 template <int I, int J, int WAVES, int F8, int NORM>
 static void launch_gemm_ij(const GemmDP& p, int epi, hipStream_t st) {
     const int Mb = (p.M + 15) / 16, MT = (Mb + J - 1) / J, NT = p.N / (16 * I);
     const dim3 g(NT * MT), b(WAVES * 64);
-    const size_t sh = (size_t)WAVES * I * J * 64 * 16 + (NORM ? (size_t)16 * (p.K + 8) * 2 : 0);
+    const size_t sh = (size_t)WAVES * I * J * 64 * 16 + (NORM == 1 ? (size_t)16 * (p.K + 8) * 2 : 0);
     static size_t attr[4] = {0, 0, 0, 0};
 #define LG(E)                                                                                                                   \
     do {                                                                                                                        \
@@ -340,6 +447,17 @@ extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStr
     if (p->N % (16 * (cfg / 100)) || p->K % 32) return -1;
     if (p->wscale && p->K % 64) return -1;
     const int f8 = p->wscale ? (p->f8_mfma ? 2 : 1) : 0;
+    if (p->ssq_in) {                                     // normalise-on-the-fly variant (NORM == 2): any tile; X = the bf16 residual rows themselves
+        if (!p->nw || !p->nh_in || epi == EPI_RESID || p->ssq_np <= 0 || (p->ssq_np & 3) || p->ssq_np > 128) return -1;
+        switch (cfg) {
+#define CASE(I, J) case I * 100 + J * 10: if (f8 == 2) launch_gemm_ij<I, J, 4, 2, 2>(*p, epi, st); else if (f8) launch_gemm_ij<I, J, 4, 1, 2>(*p, epi, st); else launch_gemm_ij<I, J, 4, 0, 2>(*p, epi, st); break; \
+                   case I * 100 + J * 10 + 1: if (f8 == 2) launch_gemm_ij<I, J, 8, 2, 2>(*p, epi, st); else if (f8) launch_gemm_ij<I, J, 8, 1, 2>(*p, epi, st); else launch_gemm_ij<I, J, 8, 0, 2>(*p, epi, st); break;
+            CASE(1, 1) CASE(1, 2) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
+#undef CASE
+            default: return -1;
+        }
+        return 0;
+    }
     if (p->nw) {                                         // fused-norm variant: one m-block
         if (p->M > 16 || (cfg / 10) % 10 != 1 || epi == EPI_RESID || p->K > 2048) return -1;
         switch (cfg) {
@@ -389,6 +507,7 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     __shared__ float red[NWAVE][66];
     const int split = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
+    STAMP(p, 0);
     const int pos = *p.pos;
     // Persistent form (n_seq > 0): every workgroup of the grid is resident from the start and walks items blockIdx.x, +gridDim.x, ...
     // A grid of thousands of (sequence, head) workgroups keeps the dispatcher busy for the whole kernel, and the OTHER decode chain's
@@ -424,13 +543,20 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
 
     // KV8: a 32-position block is 2 + 2 KiB instead of 4 + 4: two 16-byte loads per lane for K and two for V (kr[0..1], vr[0..1]), each carrying the
     // bytes of two MFMA operands
-    auto load = [&](u32x4 (&kr)[4], u32x4 (&vr)[4], int blk) {
+    // the text-pad mask bytes of a block inside the prefix are requested together with its K / V rows (they used to be fetched inside compute(), a second
+    // dependent round trip for exactly the waves that own the text blocks — the tail of the one-launch small-batch form)
+    auto load = [&](u32x4 (&kr)[4], u32x4 (&vr)[4], unsigned (&mb)[8], int blk) {
+        if (mk != nullptr && blk * 32 < p.T) {
+            const int jb = blk * 32 + q4 * 4;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mb[e] = mk[min(jb + (e < 4 ? e : 12 + e), p.T - 1)];
+        }
 #pragma unroll
         for (int i = 0; i < (KV8 ? 2 : 4); ++i) kr[i] = __builtin_nontemporal_load(Kp + ((long)blk * (KV8 ? 2 : 4) + i) * 64);
 #pragma unroll
         for (int i = 0; i < (KV8 ? 2 : 4); ++i) vr[i] = __builtin_nontemporal_load(Vp + ((long)blk * (KV8 ? 2 : 4) + i) * 64);
     };
-    auto compute = [&](const u32x4 (&kr_)[4], const u32x4 (&vr_)[4], int blk) {
+    auto compute = [&](const u32x4 (&kr_)[4], const u32x4 (&vr_)[4], const unsigned (&mb)[8], int blk) {
         u32x4 kr[4], vr[4];
         if (KV8) {
 #pragma unroll
@@ -456,7 +582,7 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
             for (int e = 0; e < 8; ++e) {
                 const int j = jb + (e < 4 ? e : 12 + e);
                 unsigned mv = 1u;
-                if (use_mk) mv = mk[min(j, p.T - 1)];
+                if (use_mk) mv = mb[e];
                 const bool ok = (j <= pos) & ((j >= p.T) | (mv != 0u));
                 sc[e] = ok ? sc[e] : -INFINITY;
             }
@@ -478,24 +604,27 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
         }
     };
     if (PF) {
-        u32x4 ka[4], va[4], kb2[4], vb2[4];
+        u32x4 ka[4], va[4], kb2[4], vb2[4]; unsigned ma[8], mb2[8];
         int blk = (jmin >> 5) + split * NWAVE + wave;
-        if (blk < nblk) load(ka, va, blk);
+        if (blk < nblk) load(ka, va, ma, blk);
         while (blk < nblk) {
             int nb = blk + NW;
-            if (nb < nblk) load(kb2, vb2, nb);
-            compute(ka, va, blk);
+            if (nb < nblk) load(kb2, vb2, mb2, nb);
+            compute(ka, va, ma, blk);
             blk = nb;
             if (blk >= nblk) break;
             nb = blk + NW;
-            if (nb < nblk) load(ka, va, nb);
-            compute(kb2, vb2, blk);
+            if (nb < nblk) load(ka, va, ma, nb);
+            compute(kb2, vb2, mb2, blk);
             blk = nb;
         }
     } else {
-        u32x4 ka[4], va[4];
-        for (int blk = (jmin >> 5) + split * NWAVE + wave; blk < nblk; blk += NW) { load(ka, va, blk); compute(ka, va, blk); }
+        u32x4 ka[4], va[4]; unsigned ma[8];
+        for (int blk = (jmin >> 5) + split * NWAVE + wave; blk < nblk; blk += NW) { load(ka, va, ma, blk); compute(ka, va, ma, blk); }
     }
+#ifdef CAR_STAMP
+    asm volatile("s_nop 0" ::"v"(l_run)); STAMP(p, 3);
+#endif
     // ---- merge: every lane of a q-group holds the same l partial; o[d][*] rows are identical (P rows are identical)
     float lt = l_run + __shfl_xor(l_run, 16, 64); lt += __shfl_xor(lt, 32, 64);
     if (q4 == 0) {
@@ -504,6 +633,7 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     }
     if (lane == 0) { red[wave][0] = m_run; red[wave][1] = lt; }
     __syncthreads();
+    STAMP(p, 4);
     if (tid < 64) {
         float M = red[0][0];
 #pragma unroll
@@ -529,6 +659,9 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     }
     if (persist) __syncthreads();       // `red` is reused by the next item
     }
+#ifdef CAR_STAMP
+    __builtin_amdgcn_s_waitcnt(0); STAMP(p, 5);
+#endif
 }
 
 // text-pad mask rows for the decode batch: out[r][t] = emb_mask[row_img[r]][t] != 0 (all ones without a mask); generate.py:184-193
@@ -592,8 +725,7 @@ extern "C" void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, in
         // without the combine kernel beats nsplit x 4 waves + combine (one dependent kernel less per layer, experiments/small_chain)
         case 80: LA(8, 0); break;
         case 81: LA(8, 1); break;
-        case 160: LA(16, 0); break;
-        case 161: LA(16, 1); break;
+        case 160: LA(16, 0); break;      // (the 16-wave prefetch form, variant 161, was measured slower in round 3 and is gone: two register sets do not fit 128 VGPRs)
         default: LA(4, 1); break;
     }
 #undef LA
@@ -648,6 +780,7 @@ extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const
 template <int NQ>
 __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    STAMP(p, 0);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
     const int D = p.D, ng = D >> 2;
@@ -656,6 +789,9 @@ __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
     const bf16_t* add = (p.add & 1) ? p.ctrl + (r * p.n_tok + (*p.pos - p.T + 1)) * D : nullptr;
     float val[NQ][4];
     float ss = 0.f;
+    uint2 wreg[NQ];        // the norm weight does not depend on the reduction: requested up front, one round trip instead of two
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int gi = lane + q * 64; if (gi < ng) wreg[q] = *(const uint2*)(p.w + gi * 4); }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int gi = lane + q * 64;
@@ -673,6 +809,9 @@ __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
         }
     }
     const float rstd = rsqrtf(wave_sum(ss) / D + p.eps);
+#ifdef CAR_STAMP
+    asm volatile("s_nop 0" ::"v"(rstd)); STAMP(p, 3);
+#endif
     const int nkb = D >> 5;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -680,7 +819,7 @@ __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
         if (gi < ng) {
             const int k = gi * 4;
             if (p.h_out) { uint2 u; u.x = pack_bf16x2(val[q][0], val[q][1]); u.y = pack_bf16x2(val[q][2], val[q][3]); *(uint2*)(p.h_out + r * D + k) = u; }
-            const uint2 wu = *(const uint2*)(p.w + k);
+            const uint2 wu = wreg[q];
             const float w[4] = {__uint_as_float(wu.x << 16), __uint_as_float(wu.x & 0xffff0000u), __uint_as_float(wu.y << 16), __uint_as_float(wu.y & 0xffff0000u)};
             float o[4];
 #pragma unroll
@@ -690,6 +829,9 @@ __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
             *(uint2*)(p.xn + off) = u;
         }
     }
+#ifdef CAR_STAMP
+    __builtin_amdgcn_s_waitcnt(0); STAMP(p, 5);
+#endif
 }
 extern "C" void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st) {
     const int nq = (p->D / 4 + 63) / 64;                      // column groups per lane (D <= 4096: every LlamaGen size)

@@ -4,6 +4,13 @@
 #include "car_common.h"
 
 #define CAR_GEMMDP_DEFINED
+// experiments/lat_probe.hip compiles the kernels with -DCAR_STAMP: every workgroup then writes wall-clock stamps of its phases (entry, first operands
+// consumed, main loop done, fold done, exit) into `stamp[slot][workgroup][8]`.  The product build has neither the fields nor the stores.
+#ifdef CAR_STAMP
+#define CAR_STAMP_FIELDS long long* stamp; int stamp_slot;
+#else
+#define CAR_STAMP_FIELDS
+#endif
 enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 
 struct GemmDP {
@@ -31,6 +38,14 @@ struct GemmDP {
     //   x = rnd(rnd(v * rsqrt(mean v^2 + eps)) * w)     — the arithmetic of rmsnorm2_kernel, gpt_t2i.py:193-198
     const bf16_t* nh_in; const bf16_t* nemb; const int* nidx; bf16_t* nh_out; const bf16_t* nw; const bf16_t* nctrl;
     int nadd, nT, n_tok; float ncs, neps;
+    // NORM == 2 kernels ("normalise on the fly", any J): X = RMSNorm(h) is never materialised.  The RESID linear that produced h left the row sums of squares
+    // as per-tile partials ssq_in[m][ssq_np]; the kernel folds them in index order into rstd[m] and turns the bf16 rows of nh_in it loads (row-major, ld = K)
+    // into X fragments in registers: x = rnd(rnd(h * rstd) * nw).  One dependent kernel and one barrier-separated prologue less than NORM == 1.
+    const float* ssq_in; int ssq_np;
+    // EPI_RESID: if set, the epilogue also writes ssq_out[m * ssq_ld + pair] = sum of the squares of the h values it STORES in row m over its pair of
+    // row-blocks (pair = row-block / 2; row-block itself for one-row-block tiles): ssq_ld = N / 32 (N / 16)
+    float* ssq_out; int ssq_ld;
+    CAR_STAMP_FIELDS
 };
 
 // =============================================================================================== attention
@@ -45,6 +60,7 @@ struct Attn2P {
     int H, SA, T, dim, nsplit, out_packed;
     int kv8;                    // the caches hold e4m3 bytes (K8 / V8 layouts), widened to bf16 in registers
     int n_seq, pgrid;           // persistent form (nsplit == 1): n_seq > 0 sequences, a 1-D grid of pgrid workgroups walks the n_seq*H items
+    CAR_STAMP_FIELDS
 };
 
 // =============================================================================================== RMSNorm -> packed xn
@@ -52,4 +68,5 @@ struct Norm2P {
     const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
     const bf16_t* ctrl; const int* pos; int add /* bit 0: add the control token, bit 1: raised wave priority */; int T; int n_tok; float cs;
     int D; float eps;
+    CAR_STAMP_FIELDS
 };

@@ -971,7 +971,7 @@ struct StepBufs { void *h, *xn, *qkv, *att, *mid, *mid2; float* part; float* log
 // A chain = a contiguous slice [b0, b0+bg) of the sequences decoded as its own dependency chain.  With several chains the
 // captured step has parallel branches: one chain's HBM-bound attention overlaps the other chains' latency-bound GEMMs
 // (each chain re-streams the weights; a layer's 40 MB sits in the 256 MiB MALL between chains).
-struct FastBufs { bf16_t *xn, *att, *mid, *q; float* logits; float* attn_part; };     // per-chain scratch (XP-packed activations)
+struct FastBufs { bf16_t *xn, *att, *mid, *q; float* logits; float* attn_part; float* ssq; };     // per-chain scratch (XP-packed activations; ssq: row sums of squares of the residual stream as per-tile partials [rows][dim/16])
 struct Grp { int b0, bg, nsplit, attn_variant, attn_lds_pad, attn_pgrid; int *pos, *step; FastBufs fb; SampleP sp; };
 
 // bf16 fast path (decode2.hip): 7 kernels per layer — norm -> wqkv(+RoPE, KV write) -> attention -> wo(+residual) ->
@@ -991,15 +991,18 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     bf16_t* h = (bf16_t*)sb.h + (size_t)b0 * D;
     const bool f8 = g.decode_weight_fp8 != 0;
     int nk = 0, bad_cfg = 0;
-    auto gemm = [&](const std::string& wname, const bf16_t* X, int N, int K, int epi, GemmDP gp_) {
+    // returns the number of sum-of-squares partials per row the kernel leaves in p.ssq_out (0 if it writes none)
+    auto gemm = [&](const std::string& wname, const bf16_t* X, int N, int K, int epi, GemmDP gp_) -> int {
         GemmDP p = gp_;
         p.W = (const bf16_t*)Wp(c, wname + (f8 ? "#pk8" : "#pk")); p.X = X; p.M = b; p.N = N; p.K = K;
         p.wscale = f8 ? (const float*)Wp(c, wname + "#sc") : nullptr; p.f8_mfma = g.decode_weight_fp8 == 2;
         const int cfg = car_pick_gemm_cfg(b, N, K, epi);
-        const int J = (cfg / 10) % 10, Mb = (b + 15) / 16;
+        const int I = cfg / 100, J = (cfg / 10) % 10, Mb = (b + 15) / 16;
         p.w_nt = ((Mb + J - 1) / J == 1 ? 1 : 0) | (prio ? 2 : 0);      // bit 0: non-temporal weight stream, bit 1: raised wave priority
+        if (p.ssq_out) p.ssq_ld = N / (16 * (I >= 2 ? 2 : 1));
         if (car_launch_dec_gemm_cfg(&p, epi, cfg, st)) bad_cfg = cfg;
         ++nk;
+        return p.ssq_out ? p.ssq_ld : 0;
     };
     GemmDP z; memset(&z, 0, sizeof(z));
     // tiny chains (<= 8 rows): the latency-bound regime (BASELINE configs 2, 4, 5).  The two RMSNorms of a layer and the final norm run
@@ -1010,8 +1013,18 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     // repeats the norm of all rows) no longer wins (44.1 either way at 12, 50.1 vs 49.4 at 16) and the separate norm kernels stay.
     // The floor of this structure is the kernel boundary itself: 5 EMPTY kernels per layer cost 8.3 us.
     const bool fuse_norm = b <= 8 && D <= 2048 && !getenv("CAR_NO_SMALL_FUSE");
+    // chains of up to 48 rows (round 4, experiments/lat_probe: profiles/r04_lat_probe_v5_*): the RMSNorm in front of wqkv / w1|w3 / output is applied ON THE FLY.
+    // The RESID linear that produced the residual stream (wo, w2) leaves each row's sum of squares as per-tile partials; the consumer folds them into rstd
+    // and normalises the bf16 residual rows it loads as its X operand in registers (dec_gemm NORM == 2).  Against the prologue form (<= 8 rows: a barrier-
+    // separated norm in front of the main loop, 3.6-6.0 us of a 6-8 us kernel) and against the separate rmsnorm2 kernels (> 8 rows: two dependent launches of
+    // ~6 us per layer) the measured layer goes 37.0 -> 34.4 us at 2 rows, 39.4 -> 35.7 at 8, 66.5 -> 61.6 at 32; at 64 rows it is a draw (83.3 / 82.9: the
+    // 960 workgroups of wqkv each repeat the row statistics) and at 128 a loss (120 / 125), so larger chains keep the norm kernels.  The first norm of layer 0
+    // (token gather) and of the three control-add layers changes the stream before it is normed: those keep the prologue / kernel form.
+    const bool normx = b <= 48 && fb.ssq != nullptr && !getenv("CAR_NO_NORMX");
+    int ssq_np = 0;                                                   // partials per row currently valid in fb.ssq (0: none)
     bf16_t* hc = h;                                                  // the residual stream; ping-pongs with `halt` when a control token is added
     bf16_t* halt = (bf16_t*)sb.xn + (size_t)b0 * D;                  // (the prefill's xn buffer is idle during decode)
+    auto normx_fields = [&](GemmDP& q, const std::string& wname) { q.nw = (const bf16_t*)Wp(c, wname); q.neps = g.norm_eps; q.nh_in = hc; q.ssq_in = fb.ssq; q.ssq_np = ssq_np; };
     auto norm_fields = [&](GemmDP& q, const std::string& wname, int l, bool first_of_layer) {
         q.nw = (const bf16_t*)Wp(c, wname); q.neps = g.norm_eps; q.nh_in = hc; q.pos = gr.pos;
         if (first_of_layer && l == 0) { q.nemb = (const bf16_t*)Wp(c, "tok_embeddings.weight"); q.nidx = sb.cur + b0; q.nh_out = h; }
@@ -1024,7 +1037,9 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         const std::string L = "layers." + std::to_string(l) + ".";
         const size_t kvb = g.kv_cache_fp8 ? 1 : 2;          // bytes per cached element (e4m3 / bf16)
         bf16_t* kc = (bf16_t*)((char*)c->kv.p + ((size_t)(2 * l) * kv_layer + kv_off) * kvb); bf16_t* vc = (bf16_t*)((char*)c->kv.p + ((size_t)(2 * l + 1) * kv_layer + kv_off) * kvb);
-        if (!fuse_norm) {   // [token gather at layer 0] (+ control add at layers 0, n/3, 2n/3) -> h ; attention_norm -> xn (packed)
+        const bool special = l == 0 || (use_ctrl && l % li == 0 && l / li < 3);      // the stream changes (gather / control add) before this layer's first norm
+        const bool nx1 = normx && !special && ssq_np > 0;
+        if (!nx1 && !fuse_norm) {   // [token gather at layer 0] (+ control add at layers 0, n/3, 2n/3) -> h ; attention_norm -> xn (packed)
             Norm2P np; memset(&np, 0, sizeof(np));
             np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps; np.add = prio ? 2 : 0;
             if (l == 0) { np.emb = (const bf16_t*)Wp(c, "tok_embeddings.weight"); np.idx = sb.cur + b0; np.h_out = h; }
@@ -1035,9 +1050,10 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         }
         {
             GemmDP q = z; q.qout = fb.q; q.kc = kc; q.vc = vc; q.rope = c->rope; q.pos = gr.pos; q.H = Hn; q.SA = SA; q.dim = D; q.kv8 = g.kv_cache_fp8 ? 1 : 0;
-            if (fuse_norm) { norm_fields(q, L + "attention_norm.weight", l, true); }
+            if (nx1) normx_fields(q, L + "attention_norm.weight");
+            else if (fuse_norm) { norm_fields(q, L + "attention_norm.weight", l, true); }
             gemm(L + "attention.wqkv.weight", fb.xn, 3 * D, D, EPI_QKV, q);
-            if (fuse_norm && q.nh_out) hc = q.nh_out;
+            if (!nx1 && fuse_norm && q.nh_out) hc = q.nh_out;
             if (l == 0 && phase_ev) { (void)hipEventRecord(phase_ev, st); (void)hipStreamWaitEvent(phase_dst, phase_ev, 0); }
         }
         {
@@ -1047,21 +1063,31 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             if (gr.attn_pgrid > 0 && nsplit == 1) { ap.n_seq = b; ap.pgrid = gr.attn_pgrid; }
             car_launch_dec_attn2_var(&ap, b, gr.attn_variant, gr.attn_lds_pad, st); nk += nsplit > 1 ? 2 : 1;
         }
-        { GemmDP q = z; q.h = hc; gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
-        if (!fuse_norm) {
+        { GemmDP q = z; q.h = hc; if (normx) q.ssq_out = fb.ssq; ssq_np = gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
+        const bool nx2 = normx && ssq_np > 0;
+        if (!nx2 && !fuse_norm) {
             Norm2P np; memset(&np, 0, sizeof(np));
             np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps; np.add = prio ? 2 : 0;
             car_launch_rmsnorm2(&np, b, st); ++nk;
         }
-        { GemmDP q = z; q.outp = fb.mid; if (fuse_norm) norm_fields(q, L + "ffn_norm.weight", l, false); gemm(L + "feed_forward.w13.weight", fb.xn, 2 * Fh, D, EPI_SWIGLU, q); }
-        { GemmDP q = z; q.h = hc; gemm(L + "feed_forward.w2.weight", fb.mid, D, Fh, EPI_RESID, q); }
+        { GemmDP q = z; q.outp = fb.mid;
+          if (nx2) normx_fields(q, L + "ffn_norm.weight"); else if (fuse_norm) norm_fields(q, L + "ffn_norm.weight", l, false);
+          gemm(L + "feed_forward.w13.weight", fb.xn, 2 * Fh, D, EPI_SWIGLU, q); }
+        {   // w2 leaves the sums of squares for the next layer's first norm (or the final norm) unless that layer adds a control token first
+            const bool next_special = l + 1 < g.n_layer && use_ctrl && (l + 1) % li == 0 && (l + 1) / li < 3;
+            GemmDP q = z; q.h = hc; if (normx && !next_special) q.ssq_out = fb.ssq;
+            ssq_np = gemm(L + "feed_forward.w2.weight", fb.mid, D, Fh, EPI_RESID, q);
+        }
     }
-    if (!fuse_norm) {
+    const bool nx3 = normx && ssq_np > 0;
+    if (!nx3 && !fuse_norm) {
         Norm2P np; memset(&np, 0, sizeof(np));
         np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps; np.add = prio ? 2 : 0;
         car_launch_rmsnorm2(&np, b, st); ++nk;
     }
-    { GemmDP q = z; q.outf = fb.logits; if (fuse_norm) norm_fields(q, "norm.weight", g.n_layer, false); gemm("output.weight", fb.xn, V, D, EPI_LOGITS, q); }
+    { GemmDP q = z; q.outf = fb.logits;
+      if (nx3) normx_fields(q, "norm.weight"); else if (fuse_norm) norm_fields(q, "norm.weight", g.n_layer, false);
+      gemm("output.weight", fb.xn, V, D, EPI_LOGITS, q); }
     car_launch_advance(gr.pos, gr.step, st); ++nk;
     SampleP sp = gr.sp; sp.logits = fb.logits; sp.logits_ks = 0; sp.round_bf16 = 0;
     car_launch_sample_greedy(&sp, st); ++nk;
@@ -1359,7 +1385,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     if (fast) {
         // per-chain scratch from one arena: XP-packed xn / att [Mb*16, D], mid [Mb*16, Fh], q [bg, D] (bf16); logits [bg, V],
         // split-KV partials (fp32).  Every slice is a multiple of 16 bytes.
-        size_t tot = 0; size_t sizes[8][6];
+        size_t tot = 0; size_t sizes[8][7];
         for (int gi = 0; gi < NG; ++gi) {
             Grp& gr = grp[gi];
             gr.b0 = mult * img0[gi]; gr.bg = mult * (img0[gi + 1] - img0[gi]);
@@ -1380,15 +1406,15 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
               if (R > 0 && R <= 16 && gr.nsplit == 1) { const long items = (long)bg * Hn, cap = (long)c->n_cu * R;
                   if (items > cap) { const long per = (items + cap - 1) / cap; gr.attn_pgrid = (int)((items + per - 1) / per); } } }
             sizes[gi][0] = M16 * D * 2; sizes[gi][1] = M16 * D * 2; sizes[gi][2] = M16 * Fh * 2; sizes[gi][3] = rup((size_t)bg * D * 2, 16);
-            sizes[gi][4] = (size_t)bg * V * 4; sizes[gi][5] = rup((size_t)bg * Hn * gr.nsplit * 66 * 4, 16);
-            for (int k = 0; k < 6; ++k) tot += sizes[gi][k];
+            sizes[gi][4] = (size_t)bg * V * 4; sizes[gi][5] = rup((size_t)bg * Hn * gr.nsplit * 66 * 4, 16); sizes[gi][6] = rup(M16 * (size_t)(D / 16) * 4, 16);
+            for (int k = 0; k < 7; ++k) tot += sizes[gi][k];
         }
         NEED(c, c->dec_parts, tot);
         char* pbase = (char*)c->dec_parts.p;
         for (int gi = 0; gi < NG; ++gi) {
             Grp& gr = grp[gi]; FastBufs& f = gr.fb;
             f.xn = (bf16_t*)pbase; pbase += sizes[gi][0]; f.att = (bf16_t*)pbase; pbase += sizes[gi][1]; f.mid = (bf16_t*)pbase; pbase += sizes[gi][2];
-            f.q = (bf16_t*)pbase; pbase += sizes[gi][3]; f.logits = (float*)pbase; pbase += sizes[gi][4]; f.attn_part = (float*)pbase; pbase += sizes[gi][5];
+            f.q = (bf16_t*)pbase; pbase += sizes[gi][3]; f.logits = (float*)pbase; pbase += sizes[gi][4]; f.attn_part = (float*)pbase; pbase += sizes[gi][5]; f.ssq = (float*)pbase; pbase += sizes[gi][6];
             gr.pos = pos + 2 * gi; gr.step = step + 2 * gi;        // scal layout: (pos, step) x 8 chains, then cur_tok[b], then jmin[b]
             gr.sp = group_sampler(gi); gr.sp.step_ptr = gr.step;
             gr.sp.logits = nullptr;     // set per launch to the chain's logits
@@ -1441,7 +1467,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
                  (const void*)forced_tokens, (void*)logits_out);
         { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
-                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid);
+                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((getenv("CAR_NO_NORMX") ? 1 : 0) + (getenv("CAR_NO_SMALL_FUSE") ? 2 : 0)));
           strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
         const bool no_graph = getenv("CAR_NO_GRAPH") != nullptr;      // profiling aid: eager launches (PMC collection cannot follow graph replays)

@@ -328,5 +328,5 @@ def test_e4m3_kv_cache_saturates_outliers():
     assert torch.isfinite(lg).all(), "an e4m3 KV outlier was stored as NaN"
     d = (lg - logits_m).abs()
     _record("kv_e4m3_outliers[tiny]", hip_vs_model_max=float(d.max()), hip_vs_model_mean=float(d.mean()))
-    assert float(d.mean()) <= 0.25 and float(d.max()) <= 2.5, (float(d.max()), float(d.mean()))
+    assert float(d.max()) <= 0.6 and float(d.mean()) <= 0.08, (float(d.max()), float(d.mean()))      # the fast mode's own tolerance (measured 0.24 / 0.027)
     eng.close()

@@ -11,7 +11,12 @@ import csv, json, os, sys
 from collections import defaultdict
 
 fetch_csv, write_csv, steps, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-DEC = ("dec_gemm_kernel", "dec_attn2", "rmsnorm2_kernel", "sample_greedy_kernel", "sample_stochastic_kernel", "advance_kernel")
+precision = sys.argv[6] if len(sys.argv) > 6 else "bf16"
+DEC = ("dec_gemm_kernel", "dec_attn2", "rmsnorm2_kernel", "sample_greedy_kernel", "sample_stochastic_kernel", "advance_kernel",
+       "dec_gemm_f32_kernel", "dec_attn_f32")      # exact mode (decode_f32.hip); its rmsnorm_kernel<float> is shared with the prefill and left out (< 0.5 % of the step's bytes)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from controlar_amd import _lib
+build_id = _lib.load().car_build_id().decode()
 
 
 def load(path, counter):
@@ -38,7 +43,7 @@ for tag, path, counter, mult in (("fetch", fetch_csv, "FETCH_SIZE", 2.0), ("writ
         tot += sum(v)
     res[tag + "_bytes_per_step"] = tot * 1024.0 * mult / steps
     print(f"{counter}: {res[tag + '_bytes_per_step'] / 1e9:.3f} GB per decode step ({steps} steps profiled)")
-rec = {"model": "xl", "batch": batch, "cfg_scale": 1.0, "precision": "bf16", "weights_fp8": False, "image_hw": [512, 512], "adapter_size": "small",
+rec = {"model": "xl", "batch": batch, "cfg_scale": 1.0, "precision": precision, "weights_fp8": False, "build_id": build_id, "image_hw": [512, 512], "adapter_size": "small",
        "steps_profiled": steps, **res,
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/pmc_workload.py at the mean decode position "
                "(CAR_DEBUG_SKIP_STEPS); FETCH_SIZE KiB x2 (gfx950 wide-read correction), WRITE_SIZE as reported; decode-loop kernels only"}
