@@ -243,7 +243,7 @@ def main():
     # at a time in a packed host buffer and sends it to its rank (dist.scatter_inputs); --input-dist local: every rank builds its own.
     G = args.batch * world
     T, cap = cfg.gpt.cls_token_num, cfg.gpt.caption_dim
-    from controlar_amd.dist import scatter_inputs
+    from controlar_amd.dist import scatter_inputs, scatter_probe, parallel_fill
 
     def make_shard(r):
         packed, h_img, h_emb, h_mask = alloc_packed_host(args.batch, Hh, Ww, T, cap)
@@ -259,8 +259,7 @@ def main():
             else:
                 e_, m_ = synth.text_embeddings(1, T, cap, seed=1234 + g_)
                 h_emb[j] = e_[0].to(torch.bfloat16); h_mask[j] = m_[0]
-        for j in range(args.batch):
-            one(j)
+        parallel_fill(args.batch, one)                       # independent per-image generators, disjoint output slices
         return packed
     t_bc0 = time.perf_counter()
     if args.input_dist == "local" or world == 1:
@@ -272,13 +271,15 @@ def main():
         dist.barrier()
     t_bcast = time.perf_counter() - t_bc0                     # host synthesis of the shards + H2D + the point-to-point sends
     shard_bytes = int(sum(__import__("controlar_amd.dist", fromlist=["packed_layout"]).packed_layout(args.batch, Hh, Ww, T, cap)))
+    # the wire half of the input edge, measured on its own (N > 1 only): rank 0 sends one shard-sized device buffer to every other rank over RCCL / xGMI
+    t_probe, probe_bytes = scatter_probe(dist, dev, rank, world, shard_bytes, sync_fn=torch.cuda.synchronize)
     img, emb, mask = img.contiguous(), emb.contiguous(), mask.contiguous()
     if args.precision == "fp32" and not c2i:
         # exact mode takes the caption features in fp32 (the packed transport buffer carries bf16): redraw this rank's rows unrounded,
         # so that row 0 is bit for bit the input of the committed XL golden (the control maps are {-1,+1}: exact in either type)
         emb = torch.stack([synth.text_embeddings(1, T, cap, seed=1234 + rank + world * j)[0][0] for j in range(args.batch)]).to(dev)
     # self-check rows: with >= 4 images the first image of the second half (the second decode chain when the batch is cut in
-    # two, engine.hip generate_impl) repeats local image 0 — identical inputs must come out as identical tokens and pixels
+    # two, engine_generate.hip generate_impl) repeats local image 0 — identical inputs must come out as identical tokens and pixels
     twin = args.batch // 2 if (args.batch >= 4 and not args.sample_logits) else -1      # sampled rows draw from their own Philox stream (seed, row, step): twins differ by design
     if twin > 0:
         img[twin], emb[twin], mask[twin] = img[0], emb[0], mask[0]
@@ -326,6 +327,7 @@ def main():
     dec_ms, pre_ms, st = acc["dec_ms"], acc["pre_ms"], acc["st"]
     # every token of every image went through the decode loop: the first comes from the prefill, the other n_new - 1 are one graph replay each
     assert st["decode_steps"] == n_new - 1, f"decode loop ran {st['decode_steps']} steps, expected {n_new - 1}"
+    assert st["dev_knobs_active"] == 0, "a CAR_* library switch is set in the environment: not the shipped schedule"
     log(f"timed region {elapsed:.2f}s")
     t_gather = 0.0
     if dist is not None:
@@ -398,6 +400,8 @@ def main():
                        "input_distribution": ("local (every rank draws its shard)" if (args.input_dist == "local" or world == 1) else
                                               "scatter from rank 0: one shard built, copied and sent point-to-point at a time"),
                        "input_distribution_s": t_bcast, "input_wire_bytes": 0 if (args.input_dist == "local" or world == 1) else shard_bytes * (world - 1),
+                       "input_scatter_probe_s": t_probe, "input_scatter_probe_bytes": probe_bytes,
+                       "input_scatter_probe_gb_per_s": (probe_bytes / t_probe / 1e9) if t_probe > 0 else None,
                        "token_gather_s": t_gather, "graph": st["graph_used"],
                        "decode_kernels_per_step": st["decode_kernels_per_step"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

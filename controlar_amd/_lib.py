@@ -51,7 +51,7 @@ class CarSampling(C.Structure):
 class CarStats(C.Structure):
     _fields_ = [
         ("decode_ms", C.c_double), ("prefill_ms", C.c_double), ("decode_steps", C.c_int64), ("decode_algo_bytes", C.c_int64),
-        ("decode_kernels_per_step", C.c_int32), ("graph_used", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("decode_kernels_per_step", C.c_int32), ("graph_used", C.c_int32), ("dev_knobs_active", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 

@@ -20,7 +20,7 @@ import torch
 
 from .config import PathConfig
 
-PACK_FORMAT = "CARPK03"          # bump together with engine.hip kPackMagic
+PACK_FORMAT = "CARPK03"          # bump together with engine_weights.hip kPackMagic
 
 
 def _torch_load(path: str, trust: bool = False):
@@ -61,7 +61,7 @@ def load_checkpoint(path: str, *, vq: bool = False, trust_pickle: bool = False) 
 # ---------------------------------------------------------------------------------------------- expected keys
 def expected_gpt_keys(cfg: PathConfig) -> List[str]:
     """Parameter names of gpt_t2i.Transformer / gpt.Transformer (incl. the HF encoder under ``adapter.model.``) that the path reads
-    (SURVEY.md §8b weight contract; engine.hip car_finalize_weights)."""
+    (SURVEY.md §8b weight contract; engine_weights.hip car_finalize_weights)."""
     g, v = cfg.gpt, cfg.vit
     keys = ["tok_embeddings.weight", "norm.weight", "output.weight", "adapter_mlp.fc1.weight", "adapter_mlp.fc2.weight",
             "condition_mlp.cap_proj.fc1.weight", "condition_mlp.cap_proj.fc2.weight"]
@@ -117,13 +117,13 @@ def expected_vq_keys(vq, side: str = "decoder") -> List[str]:
     return keys + ["encoder.norm_out.weight", "encoder.norm_out.bias", "encoder.conv_out.weight", "encoder.conv_out.bias", "quant_conv.weight", "quant_conv.bias"]
 
 
-# reference parameters/buffers that exist in the checkpoints but that inference never reads (engine.hip car_load_tensor)
+# reference parameters/buffers that exist in the checkpoints but that inference never reads (engine_weights.hip car_load_tensor)
 IGNORED_GPT = ("condition_embeddings.weight", "condition_mlp.uncond_embedding", "adapter.model.embeddings.mask_token",
                "condition_norm.weight", "freqs_cis", "causal_mask")
 
 
 def _canon_adapter_key(k: str) -> str:
-    """HF ViT/Dinov2 key spellings of transformers 5.x -> the 4.x checkpoint names (engine.hip canon_name)."""
+    """HF ViT/Dinov2 key spellings of transformers 5.x -> the 4.x checkpoint names (engine_weights.hip canon_name)."""
     if not k.startswith("adapter.model."):
         return k
     k = k.replace("adapter.model.layers.", "adapter.model.encoder.layer.")
@@ -180,7 +180,7 @@ def load_engine_from_checkpoints(engine, gpt_path: Optional[str] = None, vq_path
     if use_cache:
         cdir = cache_dir or default_cache_dir()
         os.makedirs(cdir, exist_ok=True)
-        # the images are a private format of one library build: its id is part of the key (and of the file header, engine.hip)
+        # the images are a private format of one library build: its id is part of the key (and of the file header, engine_weights.hip)
         build = engine.lib.car_build_id().decode()
         cfile = os.path.join(cdir, content_key(paths, bytes(engine._cc), engine.precision + "|" + build) + ".carpk")
         info["file"] = cfile

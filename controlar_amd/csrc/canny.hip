@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void canny_grad_nms_kernel(const unsigned char
 }
 
 // One hysteresis sweep.  `prev` = the "something changed" flag of the previous sweep: once a sweep changes nothing the fixed point is reached and
-// every later sweep of the batch exits at once (engine.hip car_canny enqueues the sweeps in batches and looks at the LAST flag of a batch only).
+// every later sweep of the batch exits at once (engine_encode.hip car_canny enqueues the sweeps in batches and looks at the LAST flag of a batch only).
 __global__ __launch_bounds__(256) void canny_hyst_kernel(unsigned char* __restrict__ map, int H, int W, const int* __restrict__ prev, int* __restrict__ changed) {
     __shared__ unsigned char t[CT + 2][CT + 2];
     __shared__ int again, any;

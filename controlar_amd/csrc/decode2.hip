@@ -4,7 +4,7 @@
 //
 //   dec_gemm   out = epi(X · W^T) for all b sequences of a chain in ONE pass over the weights (reference: the nn.Linear
 //              calls of gpt_t2i.py:264 wqkv, :289 wo, :217 w1/w3/w2, :470 output).  W is the fragment-packed image built at
-//              load time (engine.hip pack_decode_bf16); X is fragment-packed by its producer (rmsnorm / attention /
+//              load time (engine_weights.hip pack_decode_bf16); X is fragment-packed by its producer (rmsnorm / attention /
 //              SwiGLU epilogue).  A workgroup owns an (16·I n) x (16·J m) output tile over the WHOLE K; its waves split K
 //              and fold their accumulators through LDS in a fixed order (deterministic, no fp32 partials in HBM).
 //              Epilogues: QKV (bf16 round, 2-D RoPE, q -> scratch, K/V -> packed cache rows at *pos; gpt_t2i.py:264-277,
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
         }
         if (m >= p.M) continue;
         if (EPI == EPI_SWIGLU) {
-            // row-blocks alternate w1 | w3 (engine.hip car_load_tensor): v[0] = a, v[1] = c for hidden block (rb0/2 + ip)
+            // row-blocks alternate w1 | w3 (engine_weights.hip car_load_tensor): v[0] = a, v[1] = c for hidden block (rb0/2 + ip)
             float s[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

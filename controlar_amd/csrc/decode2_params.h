@@ -1,4 +1,4 @@
-// decode2_params.h — the parameter blocks of the decode-step kernels (decode2.hip), shared with their only caller (engine.hip) and with the standalone
+// decode2_params.h — the parameter blocks of the decode-step kernels (decode2.hip), shared with their only caller (engine_generate.hip) and with the standalone
 // harnesses under experiments/: ONE definition, so a field added on one side cannot silently shift the layout the other side fills.
 #pragma once
 #include "car_common.h"
@@ -19,7 +19,7 @@ struct GemmDP {
     int M, N, K;
     int w_nt;             // bit 0: stream W with the non-temporal policy (single M tile: each byte is used once); bit 1: raise the wave priority (s_setprio 3)
     int f8_mfma;          // F8 kernels: 1 = quantise the X fragments to e4m3 in registers and multiply on v_mfma_f32_16x16x32_fp8_fp8 (W8A8), 0 = widen W to bf16
-    const float* wscale;  // F8 kernels: per-output-row fp32 scale of the e4m3 weight image [N/16][K/64][64][16 B] (engine.hip upload_packed_fp8)
+    const float* wscale;  // F8 kernels: per-output-row fp32 scale of the e4m3 weight image [N/16][K/64][64][16 B] (engine_weights.hip dev_linear)
     // EPI_RESID: h[m][n] (row-major, ld = N) updated in place
     bf16_t* h;
     // EPI_SWIGLU: packed [ceil(M/16)][(N/2)/32][64][8]

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(F32_WAVES * 64) void dec_gemm_f32_kernel(GemmFP p) 
         for (int ii = 0; ii < IW; ++ii) v[ii] = fold(ip * IW + ii, j);
         if (m >= p.M) continue;
         if (EPI == FEPI_SWIGLU) {
-            // row-blocks alternate w1 | w3 (engine.hip car_load_tensor): v[0] = a, v[1] = c of hidden block (rb0/2 + ip)
+            // row-blocks alternate w1 | w3 (engine_weights.hip car_load_tensor): v[0] = a, v[1] = c of hidden block (rb0/2 + ip)
             f4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = silu_f(v[0][r]) * v[IW - 1][r];

@@ -1,4 +1,4 @@
-// decode_f32_params.h — parameter blocks of the exact-mode (fp32, bit-identical tokens) decode kernels of decode_f32.hip, shared with engine.hip
+// decode_f32_params.h — parameter blocks of the exact-mode (fp32, bit-identical tokens) decode kernels of decode_f32.hip, shared with engine_generate.hip
 // and the harness experiments/f32_check.hip: ONE definition.
 #pragma once
 #include "car_common.h"

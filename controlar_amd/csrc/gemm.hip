@@ -803,86 +803,95 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmP p) {
 }
 
 // host launchers -------------------------------------------------------------------------
-// Will car_launch_gemm(mode, AMODE_CONV3, p) take conv3_halo64_kernel — the kernel whose epilogue can also write the GroupNorm stage-1 partials of its
-// output (GemmP::gn_part)?  engine.hip asks before it lets the next GroupNorm skip its read-only pass.
-extern "C" int car_conv3_halo64_ok(int mode, const GemmP* pp) {
-    const GemmP& p = *pp;
-    return mode == 1 && p.Cin % 128 == 0 && (p.Ho & 15) == 0 && (p.Wo & 15) == 0 && (p.ups == 0 || p.ups == 1) && p.K == 9 * p.Cin && p.ldw % 8 == 0 &&
-           (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.W % 16 == 0 && !p.swiglu && !p.out_f32 && p.act == ACT_NONE && (p.nb0 <= 1) && (p.nb1 <= 1) && p.alpha == 1.0f &&
-           p.N % 128 == 0 && !p.scale && p.bias_mode != BIAS_M && p.ldc % 8 == 0 && (!p.R || p.ldr % 8 == 0) &&
-           !getenv("CAR_GEMM_V1") && !getenv("CAR_NO_HALO") && !getenv("CAR_CONV_HALO128") && !getenv("CAR_GN_UNFUSED");
+// ONE predicate decides whether a 3x3 convolution takes the LDS-halo kernels (conv3_halo64_kernel / conv3_halo_kernel) — shape, alignment, the A/B switches,
+// the device ordinal and the zero page of the LDS-DMA loader: car_conv3_halo64_ok (what engine_vq.hip asks before it lets the next GroupNorm skip its
+// read-only pass) and car_launch_gemm both call it, so the two cannot disagree.
+static void* g_zero_page[16] = {};
+static void* zero_page_for(int dev) {
+    if (dev < 0 || dev >= 16) return nullptr;
+    if (!g_zero_page[dev]) { if (hipMalloc(&g_zero_page[dev], 256) == hipSuccess) (void)hipMemset(g_zero_page[dev], 0, 256); else { g_zero_page[dev] = nullptr; (void)hipGetLastError(); } }
+    return g_zero_page[dev];
 }
-extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_t st) {
+static bool conv3_halo_plan(int mode, int amode, const GemmP& p, int* dev_out, void** zero_out) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev_out) *dev_out = dev;
+    if (!(mode == 1 && amode == AMODE_CONV3 && p.Cin % 128 == 0 && (p.Ho & 15) == 0 && (p.Wo & 15) == 0 && (p.ups == 0 || p.ups == 1) && p.K == 9 * p.Cin && p.ldw % 8 == 0 &&
+          (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.W % 16 == 0 && !p.swiglu && !p.out_f32 && p.act == ACT_NONE && (p.nb0 <= 1) && (p.nb1 <= 1) && p.alpha == 1.0f &&
+          p.N % 128 == 0 && !p.scale && p.bias_mode != BIAS_M && p.ldc % 8 == 0 && (!p.R || p.ldr % 8 == 0) && !getenv("CAR_GEMM_V1") && !getenv("CAR_NO_HALO"))) return false;
+    void* z = zero_page_for(dev);
+    if (zero_out) *zero_out = z;
+    return z != nullptr;
+}
+// the 64-channel-group kernel (the only one whose epilogue writes GroupNorm partials, GemmP::gn_part)
+extern "C" int car_conv3_halo64_ok(int mode, const GemmP* pp) {
+    return conv3_halo_plan(mode, AMODE_CONV3, *pp, nullptr, nullptr) && !getenv("CAR_CONV_HALO128") && !getenv("CAR_GN_UNFUSED");
+}
+// returns 0, or -1 when GemmP::gn_part is set on a call that cannot take conv3_halo64_kernel (the caller did not ask car_conv3_halo64_ok): nothing is launched
+extern "C" int car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_t st) {
     GemmP p = *pp;
     if (p.nb0 <= 0) p.nb0 = 1;
     if (p.nb1 <= 0) p.nb1 = 1;
     if (mode == 1) {
         if (amode != AMODE_CONV3 || (p.Ho & 15) || (p.Wo & 15) || getenv("CAR_CONV_LINEAR")) p.patch = 0;
         dim3 g((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nb0 * p.nb1);
-        // LDS-DMA kernel for the big GEMMs (>= 1 tile of 256 rows per CU) whenever every 16-byte chunk it fetches is aligned and whole
-        static void* zero_page[16] = {};
-        static bool attr_set = false;
-        int dev = 0; (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 16 && !zero_page[dev]) { if (hipMalloc(&zero_page[dev], 256) == hipSuccess) (void)hipMemset(zero_page[dev], 0, 256); else zero_page[dev] = nullptr; }
-        // 3x3 conv with the input halo resident in LDS (conv3_halo_kernel): stride 1, optional folded x2 upsample
-        if (amode == AMODE_CONV3 && dev >= 0 && dev < 16 && zero_page[dev] && p.Cin % 128 == 0 && (p.Ho & 15) == 0 && (p.Wo & 15) == 0 && (p.ups == 0 || p.ups == 1) &&
-            p.K == 9 * p.Cin && p.ldw % 8 == 0 && (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.W % 16 == 0 && !p.swiglu && !p.out_f32 && p.act == ACT_NONE &&
-            p.nb0 * p.nb1 == 1 && p.alpha == 1.0f && p.N % 128 == 0 && !p.scale && p.bias_mode != BIAS_M && p.ldc % 8 == 0 && (!p.R || p.ldr % 8 == 0) &&
-            !getenv("CAR_GEMM_V1") && !getenv("CAR_NO_HALO")) {
-            p.zero = zero_page[dev];
+        // dynamic-LDS attributes are per device (a one-process multi-GPU host launches on several)
+        static bool attr_set[16] = {}, attr3[16] = {}, attr4[16] = {};
+        int dev = 0; void* zero = nullptr;
+        // 3x3 conv with the input halo resident in LDS: stride 1, optional folded x2 upsample
+        if (conv3_halo_plan(mode, amode, p, &dev, &zero)) {
+            p.zero = zero;
             const dim3 g3((p.N + BN - 1) / BN, (unsigned)((long)p.M / 256));
-            if (p.gn_part && getenv("CAR_CONV_HALO128")) { fprintf(stderr, "car_launch_gemm: GemmP::gn_part needs conv3_halo64_kernel\n"); abort(); }
-            if (!getenv("CAR_CONV_HALO128")) {          // default: the 75-KB form, two workgroups per CU (A/B switch: CAR_CONV_HALO128=1 -> the 131-KB kernel)
-                static bool attr4 = false;
+            const bool halo128 = getenv("CAR_CONV_HALO128") != nullptr;
+            if (p.gn_part && (halo128 || getenv("CAR_GN_UNFUSED"))) return -1;
+            if (!halo128) {          // default: the 75-KB form, two workgroups per CU (A/B switch: CAR_CONV_HALO128=1 -> the 131-KB kernel)
                 const size_t sh4 = (size_t)(CH64_HALO_PIX * 64 + 2 * BN * G2_BK) * 2;
-                if (!attr4) {
+                if (!attr4[dev]) {
                     (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
                     (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
                     (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
                     (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh4);
-                    attr4 = true;
+                    attr4[dev] = true;
                 }
                 if (p.ups == 0) { if (p.gn_part) hipLaunchKernelGGL((conv3_halo64_kernel<0, 1>), g3, dim3(512), sh4, st, p); else hipLaunchKernelGGL((conv3_halo64_kernel<0, 0>), g3, dim3(512), sh4, st, p); }
                 else { if (p.gn_part) hipLaunchKernelGGL((conv3_halo64_kernel<1, 1>), g3, dim3(512), sh4, st, p); else hipLaunchKernelGGL((conv3_halo64_kernel<1, 0>), g3, dim3(512), sh4, st, p); }
-                return;
+                return 0;
             }
-            static bool attr3 = false;
             const size_t sh3 = (size_t)(CH_HALO_MAX * 128 + 3 * BN * G2_BK) * 2;
-            if (!attr3) {
+            if (!attr3[dev]) {
                 (void)hipFuncSetAttribute((const void*)conv3_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3);
                 (void)hipFuncSetAttribute((const void*)conv3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3);
-                attr3 = true;
+                attr3[dev] = true;
             }
             if (p.ups == 0) hipLaunchKernelGGL(conv3_halo_kernel<0>, g3, dim3(512), sh3, st, p);
             else hipLaunchKernelGGL(conv3_halo_kernel<1>, g3, dim3(512), sh3, st, p);
-            return;
+            return 0;
         }
-        if (p.gn_part) { fprintf(stderr, "car_launch_gemm: GemmP::gn_part set but the call does not take conv3_halo64_kernel (ask car_conv3_halo64_ok first)\n"); abort(); }
+        if (p.gn_part) return -1;
         const bool al16 = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && p.ldw % 8 == 0 && p.sW0 % 8 == 0 && p.sW1 % 8 == 0 && p.sA0 % 8 == 0 && p.sA1 % 8 == 0;
         const long tiles = (long)((p.N + BN - 1) / BN) * ((p.M + G2_BM - 1) / G2_BM) * p.nb0 * p.nb1;
+        (void)hipGetDevice(&dev);
         const bool ok2 = dev >= 0 && dev < 16 && p.K % G2_BK == 0 && p.K >= 512 && al16 && tiles >= 512 && !getenv("CAR_GEMM_V1") &&
                          (amode == AMODE_PLAIN ? p.lda % 8 == 0 : (amode == AMODE_CONV3 && p.Cin % G2_BK == 0));
         if (ok2) {
             const size_t sh = (size_t)G2_NS * G2_STAGE * 2;
-            if (!attr_set) {
+            if (!attr_set[dev]) {
                 (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AMODE_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
                 (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AMODE_CONV3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-                attr_set = true;
+                attr_set[dev] = true;
             }
-            if (!zero_page[dev]) { if (hipMalloc(&zero_page[dev], 256) == hipSuccess) (void)hipMemset(zero_page[dev], 0, 256); else zero_page[dev] = nullptr; }
-            if (zero_page[dev]) {
-                p.zero = zero_page[dev];
+            if ((zero = zero_page_for(dev)) != nullptr) {
+                p.zero = zero;
                 dim3 g2((p.N + BN - 1) / BN, (p.M + G2_BM - 1) / G2_BM, p.nb0 * p.nb1);
                 if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_bf16_glds_kernel<AMODE_PLAIN>, g2, dim3(512), sh, st, p);
                 else hipLaunchKernelGGL(gemm_bf16_glds_kernel<AMODE_CONV3>, g2, dim3(512), sh, st, p);
-                return;
+                return 0;
             }
         }
         if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);
         else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm_bf16_kernel<AMODE_CONV3>, g, dim3(256), 0, st, p);
     } else {
-        if (p.gn_part) { fprintf(stderr, "car_launch_gemm: GemmP::gn_part is a bf16 conv3_halo64_kernel feature\n"); abort(); }
+        if (p.gn_part) return -1;                 // GroupNorm partials are a bf16 conv3_halo64_kernel feature
         p.patch = 0;                              // the exact-mode kernel enumerates pixels linearly
         // exact mode: fp32 MFMA tiles (16 x the VALU rate per CU); the round-1 VALU kernel serves the shapes whose strides break the loader's 16-byte chunks
         const bool mfma_ok = p.K % 16 == 0 && p.ldw % 4 == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && p.sA0 % 4 == 0 && p.sA1 % 4 == 0 && p.sW0 % 4 == 0 && p.sW1 % 4 == 0 &&
@@ -892,11 +901,12 @@ extern "C" void car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_
             if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_f32_mfma_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);
             else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_f32_mfma_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);
             else hipLaunchKernelGGL(gemm_f32_mfma_kernel<AMODE_CONV3>, g, dim3(256), 0, st, p);
-            return;
+            return 0;
         }
         dim3 g((p.N + 63) / 64, (p.M + 63) / 64, p.nb0 * p.nb1);
         if (amode == AMODE_PLAIN) hipLaunchKernelGGL(gemm_f32_kernel<AMODE_PLAIN>, g, dim3(256), 0, st, p);
         else if (amode == AMODE_CONV3S2) hipLaunchKernelGGL(gemm_f32_kernel<AMODE_CONV3S2>, g, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm_f32_kernel<AMODE_CONV3>, g, dim3(256), 0, st, p);
     }
+    return 0;
 }

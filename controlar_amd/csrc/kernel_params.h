@@ -1,5 +1,5 @@
-// kernel_params.h — parameter blocks of the kernels in ops.hip / attn.hip, shared with their caller (engine.hip): ONE definition each
-// (engine.hip used to keep hand-synchronised copies).  decode2.hip's blocks live in decode2_params.h.
+// kernel_params.h — parameter blocks of the kernels in ops.hip / attn.hip, shared with their callers (engine_*.hip): ONE definition each
+// (the engine used to keep hand-synchronised copies).  decode2.hip's blocks live in decode2_params.h.
 #pragma once
 #include "car_common.h"
 

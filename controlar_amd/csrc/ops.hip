@@ -65,7 +65,7 @@ __global__ void label_index_kernel(const int64_t* labels, const int* row_img, co
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b) return;
     int64_t l = row_unc[i] ? (int64_t)num_classes : labels[row_img[i]];
-    if (l < 0 || l > num_classes) { __hip_atomic_store(err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); l = num_classes; }   // host-mapped sticky flag (engine.hip check_sticky)
+    if (l < 0 || l > num_classes) { __hip_atomic_store(err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); l = num_classes; }   // host-mapped sticky flag (engine_internal.h check_sticky)
     idx[i] = (int)l;
 }
 extern "C" void car_launch_label_index(const int64_t* labels, const int* row_img, const int* row_unc, int num_classes, int* idx, int* err_flag, int b, hipStream_t st) {

@@ -1,7 +1,7 @@
 // t5.hip — kernels specific to the caption encoder front-end: the reference's T5Embedder
 // (language/t5.py:58-79, get_text_embeddings :185-201) runs HF T5EncoderModel (Flan-T5-XL) over 120 padded token ids and
 // hands `last_hidden_state` + the attention mask to generate().  The encoder stack itself is GEMMs + RMSNorm from gemm.hip /
-// ops.hip (car_t5_encode in engine.hip); what is T5-only lives here:
+// ops.hip (car_t5_encode in engine_t5.hip); what is T5-only lives here:
 //   t5_prep          int64 ids / mask (tokenizer output) -> int32 row indices of `shared.weight` + uint8 key mask
 //   t5_softmax       P = softmax(S + position_bias[h] + (1 - mask[b]) * finfo.min) over keys, the three-term sum of HF's
 //                    T5Attention.forward / eager path (modeling_t5.py: scores += position_bias; mask added to position_bias),

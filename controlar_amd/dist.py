@@ -130,6 +130,58 @@ def scatter_inputs(dist, device, rank: int, world: int, n_local: int, H: int, W:
     return packed_views(mine, n_local, H, W, T, cap)
 
 
+def scatter_probe(dist, device, rank: int, world: int, nbytes: int, src: int = 0, sync_fn=None):
+    """The wire half of scatter_inputs alone: rank `src` sends ONE pre-built shard-sized device buffer to every other rank point-to-point (<= 1 GiB slices),
+    bracketed by barriers; returns (seconds as the MAX over ranks, bytes that crossed the wire) or (0.0, 0) for a single process.  bench.py runs it beside the
+    default `--input-dist local` so that north_star's input edge (T5 / control embeddings from the rank that owns them, over RCCL / xGMI) gets a hardware
+    number without the host-side synthesis cost of building W real shards on one rank."""
+    import time
+    if dist is None or not dist.is_initialized() or world <= 1:
+        return 0.0, 0
+    sync = sync_fn if sync_fn is not None else (lambda: None)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if rank == src:
+        buf.fill_(rank + 1)
+    sync(); dist.barrier(); sync()
+    t0 = time.perf_counter()
+    if rank == src:
+        for r in range(world):
+            if r != src:
+                for o in range(0, nbytes, BCAST_CHUNK):
+                    dist.send(buf[o:o + BCAST_CHUNK], dst=r)
+    else:
+        for o in range(0, nbytes, BCAST_CHUNK):
+            dist.recv(buf[o:o + BCAST_CHUNK], src=src)
+    sync(); dist.barrier(); sync()
+    t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert int(buf[0].item()) == src + 1 and int(buf[-1].item()) == src + 1        # the payload arrived
+    return float(t.item()), nbytes * (world - 1)
+
+
+def parallel_fill(n: int, fill_one, workers: int = 0):
+    """fill_one(j) for j in range(n) on a small thread pool with torch's intra-op pool pinned to one thread (the per-image draws of bench.py are
+    independent seeded generators writing disjoint slices; torch's CPU ops release the GIL).  Cuts the start-up of a 768-image shard from ~32 s to a few
+    seconds on the GPU box's host — eight ranks of one node do this at the same time."""
+    import concurrent.futures as cf
+    if workers <= 0:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        workers = max(1, min(16, cores // max(world, 1)))
+    if workers == 1 or n < 4:
+        for j in range(n):
+            fill_one(j)
+        return workers
+    prev = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        with cf.ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(fill_one, range(n)))
+    finally:
+        torch.set_num_threads(prev)
+    return workers
+
+
 def gather_tokens(dist, local_tokens: torch.Tensor) -> torch.Tensor:
     """all_gather of the per-rank token blocks, re-interleaved to global image order
     (inverse of shard_slice)."""

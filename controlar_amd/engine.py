@@ -255,7 +255,7 @@ class Engine:
         self._check(self.lib.car_get_stats(self._h, C.byref(s)), "car_get_stats")
         return dict(decode_ms=s.decode_ms, prefill_ms=s.prefill_ms, decode_steps=s.decode_steps,
                     decode_algo_bytes=s.decode_algo_bytes, decode_kernels_per_step=s.decode_kernels_per_step,
-                    graph_used=bool(s.graph_used))
+                    graph_used=bool(s.graph_used), dev_knobs_active=int(s.dev_knobs_active))
 
     def control_tokens(self, k: int, b: int, n_tok: int) -> torch.Tensor:
         n = b * n_tok * self.cfg.gpt.dim

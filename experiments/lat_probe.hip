@@ -1,5 +1,5 @@
 // experiments/lat_probe.hip — WHERE does a decode layer's time go?  The product's decode kernels (controlar_amd/csrc/decode2.hip compiled with -DCAR_STAMP:
-// every workgroup writes 100-MHz wall-clock stamps of its phases) run as the layer chain engine.hip builds — captured into a hipGraph of NL distinct layers,
+// every workgroup writes 100-MHz wall-clock stamps of its phases) run as the layer chain engine_generate.hip builds — captured into a hipGraph of NL distinct layers,
 // replayed — and the stamps of one replay are reduced to a timeline per kernel of a middle layer:
 //   gap     first workgroup entry of this kernel minus the last workgroup exit of the previous one (the dependent-kernel boundary)
 //   ramp    median entry minus first entry (dispatch spread over the grid)
@@ -38,7 +38,7 @@ static void layer(const Dims& d, const Bufs& b, int l, int NL, hipStream_t st, i
     bf16_t* w = b.W + b.per_layer * (l % NL);
     bf16_t *wqkv = w, *wo = w + (size_t)3 * D * D, *w13 = wo + (size_t)D * D, *w2 = w13 + (size_t)2 * Fh * D;
     bf16_t* kc = b.kv + b.kvper * 2 * (l % NL); bf16_t* vc = kc + b.kvper;
-    const bool fuse = M <= 8, nx = g_normx && M <= 128;        // nx: engine.hip's normalise-on-the-fly flow (every layer but 0 / the control-add layers)
+    const bool fuse = M <= 8, nx = g_normx && M <= 128;        // nx: engine_generate.hip's normalise-on-the-fly flow (every layer but 0 / the control-add layers)
     auto slot = [&](const std::string& n, int wgs) { g_k.push_back({n, wgs}); return (int)g_k.size() - 1; };
     auto gemm = [&](const char* nm, const bf16_t* W, const bf16_t* X, int N, int K, int epi, GemmDP p) {
         p.W = W; p.X = X; p.M = M; p.N = N; p.K = K;

@@ -231,7 +231,9 @@ typedef struct car_stats {
     int64_t decode_algo_bytes;  /* algorithmic HBM bytes of that loop (weights once/step + valid KV), DESIGN.md §4 */
     int32_t decode_kernels_per_step;
     int32_t graph_used;
-    int32_t reserved[6];
+    int32_t dev_knobs_active;   /* number of CAR_* environment variables set in this process: the library's A/B and profiling switches.  A
+                                   measurement is only the benchmark when this is 0 — bench.py refuses to run otherwise */
+    int32_t reserved[5];
 } car_stats;
 int car_get_stats(car_ctx* ctx, car_stats* out);
 

@@ -91,7 +91,7 @@ def test_xl_base_depth_cfg4_b64_vs_oracle_steps():
 @pytest.mark.parametrize("prec,B,atol,mtol", [("bf16", 33, 0.6, 0.04), ("fp32", 17, 2e-3, 1e-4)])
 def test_vq16_real_512_in_batch_chunks(prec, B, atol, mtol):
     """32x32 tokens -> 512x512 pixels through the real VQ-16 decoder; B is one more than the activation-chunk size
-    (engine.hip car_vq_decode: 32 images in bf16, 15-16 in fp32), the golden tokens sit in the first and the last chunk."""
+    (engine_vq.hip car_vq_decode: 32 images in bf16, 15-16 in fp32), the golden tokens sit in the first and the last chunk."""
     from controlar_amd import config as C, synth
     from controlar_amd.engine import Engine
     gold = np.load(os.path.join(GOLDEN, "vq16_real_32x32.npz"))

@@ -52,11 +52,18 @@ def _t2i_golden(name, mk, control):
     return cfg, gold, gsd, img, emb, mask, B, H, W
 
 
-@pytest.mark.parametrize("name,control", [("b_mr_768x512_cfg4", "canny"), ("b_depth_base_256_cfg1p5", "smooth")])
+@pytest.mark.parametrize("name,control", [("b_mr_768x512_cfg4", "canny"), ("b_depth_base_256_cfg1p5", "smooth"),
+                                          ("xl_canny_512_cfg4", "canny"), ("xl_mr_768x512_cfg4", "canny")])
 def test_t2i_goldens_at_model_size_exact_and_fast(name, control):
+    """Reference-minted goldens at model size.  GPT-B: BASELINE config 4's geometry and the real DINOv2-base encoder.  GPT-XL (round 4): BASELINE config 2 as the
+    reference runs it (sample_t2i.py:207: cfg_scale 4, one image = 2 rows, 1024 tokens) and config 4 at full width (sample_t2i_MR.py:73-78,182-185: 768x512 = 1536
+    tokens on a rope grid of 48, S_max 1656) — exact mode: every token of the reference's greedy sequence, late positions under CFG included; fast mode:
+    teacher-forced within the tolerance calibrated on the reference's own bf16 path at XL (tests/golden/xl_canny_512_cfg1_refbf16.npz) scaled by the CFG factor k."""
     from controlar_amd import config as C
     from controlar_amd.engine import Engine
-    mk = (lambda: C.b_t2i(2304, "small", "canny")) if name.startswith("b_mr") else (lambda: C.b_t2i(256, "base", "depth"))
+    mk = {"b_mr_768x512_cfg4": lambda: C.b_t2i(2304, "small", "canny"), "b_depth_base_256_cfg1p5": lambda: C.b_t2i(256, "base", "depth"),
+          "xl_canny_512_cfg4": lambda: C.xl_t2i(1024, "small", "canny"), "xl_mr_768x512_cfg4": lambda: C.xl_t2i(2304, "small", "canny")}[name]
+    xl = name.startswith("xl_")
     cfg, gold, gsd, img, emb, mask, B, H, W = _t2i_golden(name, mk, control)
     n_new = (H // 16) * (W // 16)
     s_, cstr = float(gold["cfg_scale"]), float(gold["control_strength"])
@@ -86,9 +93,15 @@ def test_t2i_goldens_at_model_size_exact_and_fast(name, control):
     d = np.abs(logits.cpu().numpy()[:, steps][:, :, ::4] - gold["logits"])
     agree = toks.cpu().numpy() == gold["tokens"]
     _record(f"fast[{name}]", max_abs_diff=d.max(), mean_abs_diff=d.mean(), k=k, argmax_agreement=float(agree.mean()))
-    assert d.max() <= 0.6 * k and d.mean() <= 0.08 * k, (d.max(), d.mean(), k)
-    # an arg-max can only flip where the reference's top-2 margin is below the sum of two logit errors: with the per-logit bound 0.6 k that is 1.2 k
-    assert agree[gold["margin"] > 1.2 * k].all() and agree.mean() > 0.85, agree.mean()
+    if xl:      # 36 layers: the reference's own bf16 path sits 1.45 / 0.24 from its fp32 logits at cfg 1 (91.6 % arg-max agreement); 1.5 x that, times k
+        cal = np.load(os.path.join(GOLDEN, "xl_canny_512_cfg1_refbf16.npz"))
+        lim_max, lim_mean = 1.5 * float(cal["ref_bf16_max"]) * k, 1.5 * float(cal["ref_bf16_mean"]) * k
+        assert d.max() <= lim_max and d.mean() <= lim_mean, (d.max(), d.mean(), lim_max, lim_mean)
+        assert agree[gold["margin"] > 2 * lim_max].all() and agree.mean() > 0.8, agree.mean()
+    else:
+        assert d.max() <= 0.6 * k and d.mean() <= 0.08 * k, (d.max(), d.mean(), k)
+        # an arg-max can only flip where the reference's top-2 margin is below the sum of two logit errors: with the per-logit bound 0.6 k that is 1.2 k
+        assert agree[gold["margin"] > 1.2 * k].all() and agree.mean() > 0.85, agree.mean()
     eng.close()
 
 

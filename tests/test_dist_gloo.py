@@ -127,7 +127,9 @@ def _scatter_worker(rank, world, port, n_local, q):
     img, emb, mask = cdist.scatter_inputs(dist, torch.device("cpu"), rank, world, n_local, H, W, T, cap, make_shard)
     local = (img.float().sum(dim=(1, 2, 3)).round().to(torch.int32)[:, None] + mask.sum(dim=1).to(torch.int32)[:, None] + torch.arange(5, dtype=torch.int32)[None])
     allt = cdist.gather_tokens(dist, local)
-    q.put((rank, allt.clone(), emb.float().abs().sum().item(), list(built)))
+    # the wire-only probe bench.py runs beside `--input-dist local`: one shard-sized buffer from rank 0 to every other rank, MAX-over-ranks time
+    t_probe, wire = cdist.scatter_probe(dist, torch.device("cpu"), rank, world, 3 * 4096 + 8)
+    q.put((rank, allt.clone(), emb.float().abs().sum().item(), list(built), t_probe, wire))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -150,11 +152,34 @@ def test_scatter_shards_gather_world2():
     emb, mask = synth.text_embeddings(G, 12, 64)
     want = (img.float().sum(dim=(1, 2, 3)).round().to(torch.int32)[:, None] + mask.sum(dim=1).to(torch.int32)[:, None] +
             torch.arange(5, dtype=torch.int32)[None])
-    for rank, allt, esum, built in res:
+    assert len({r[4] for r in res}) == 1 and res[0][4] > 0 and all(r[5] == (3 * 4096 + 8) * (world - 1) for r in res)      # same (max) time on every rank; (W-1) shards on the wire
+    for rank, allt, esum, built, _t, _w in res:
         assert torch.equal(allt, want), rank
         assert built == ([0, 1] if rank == 0 else []), (rank, built)               # only the owner builds shards, in rank order
         mine = emb[rank::world].to(torch.bfloat16).float().abs().sum().item()
         assert abs(esum - mine) < 1e-3, rank                                        # each rank holds ITS shard, not the global batch
+
+
+def test_parallel_fill_draws_the_same_shard():
+    """bench.py draws its per-image inputs on a thread pool (controlar_amd.dist.parallel_fill): independent seeded generators, disjoint slices —
+    the shard must be byte-identical to the serial draw, and a single process reports a zero-byte scatter probe."""
+    from controlar_amd import synth
+    import controlar_amd.dist as cdist
+    n, H, W, T, cap = 12, 32, 32, 12, 64
+    outs = []
+    for workers in (1, 4):
+        packed, h_img, h_emb, h_mask = cdist.alloc_packed_host(n, H, W, T, cap)
+
+        def one(j):
+            h_img[j] = synth.canny_like_control(1, H, W, seed=1234 + j, dtype=torch.bfloat16)[0]
+            e_, m_ = synth.text_embeddings(1, T, cap, seed=1234 + j)
+            h_emb[j] = e_[0].to(torch.bfloat16); h_mask[j] = m_[0]
+        before = torch.get_num_threads()
+        assert cdist.parallel_fill(n, one, workers=workers) == workers
+        assert torch.get_num_threads() == before
+        outs.append(packed.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert cdist.scatter_probe(None, torch.device("cpu"), 0, 1, 1024) == (0.0, 0)
 
 
 def test_gpus_flag_respawns_under_torchrun():

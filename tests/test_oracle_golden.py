@@ -85,6 +85,26 @@ def test_oracle_matches_reference_fp32_at_model_size(name, mk, golden_dir):
     np.testing.assert_allclose(st["ctrl"][2].numpy()[:B, ::7, ::5], gold["ctrl2"], atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("name,mk", [("xl_canny_512_cfg4", lambda: C.xl_t2i(1024, "small", "canny")),
+                                     ("xl_mr_768x512_cfg4", lambda: C.xl_t2i(2304, "small", "canny"))])
+def test_oracle_prefix_of_the_xl_cfg4_goldens(name, mk, golden_dir):
+    """GPT-XL under the reference's default guidance (cfg 4: BASELINE config 2) and at BASELINE config 4's full multi-resolution size: the whole image costs the CPU
+    5-15 minutes, so the oracle is pinned here on the control stages, the prefill (step-0 logits) and the first 12 greedy tokens; every later position of these
+    goldens is checked on the GPU against the reference directly (tests/test_configs_gpu.py::test_t2i_goldens_at_model_size_exact_and_fast, exact mode)."""
+    cfg = mk()
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    B, H, W, seed, img, emb, mask = _inputs(cfg, gold, "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=seed)
+    n = 12
+    toks, logits, st = O.generate(gsd, cfg, emb, n, mask, cfg_scale=float(gold["cfg_scale"]), condition=img,
+                                  control_strength=float(gold["control_strength"]), return_logits=True, return_stages=True)
+    assert np.array_equal(toks.numpy(), gold["tokens"][:, :n])
+    assert int(gold["logits_steps"][0]) == 0
+    np.testing.assert_allclose(logits.numpy()[:, 0, ::4], gold["logits"][:, 0], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(st["adapter_mlp_out"].numpy()[:, ::7, ::5], gold["adapter_mlp_out"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(st["ctrl"][2].numpy()[:B, ::7, ::5], gold["ctrl2"], atol=2e-4, rtol=1e-4)
+
+
 def test_oracle_vq16_real_arch(golden_dir):
     gold = np.load(os.path.join(golden_dir, "vq16_real_8x8.npz"))
     cfg = C.VQConfig()

@@ -122,7 +122,7 @@ def test_generate_is_deterministic_and_repeatable():
     eng.close()
 
 
-def test_exact_mode_is_batch_invariant():
+def test_exact_mode_is_batch_invariant(monkeypatch):
     """Exact mode: a sequence decodes to the same BITS alone and as a row of a larger batch (logits included) — every exact-mode kernel sums one
     fixed-order fp32 chain per output and the split-KV attention always folds 16 partials (a batch-dependent split count would fold a row's
     softmax partial sums in another order).  At XL the same property is checked by `bench.py --precision fp32`: row 0 of a batch of 192 must
@@ -142,6 +142,14 @@ def test_exact_mode_is_batch_invariant():
     for r in range(reps):
         assert torch.equal(t2[r * B:(r + 1) * B], t1), r
         assert torch.equal(l2[r * B:(r + 1) * B], l1), r
+    # the two-chain schedule of large exact batches (engine_generate.hip: from 192 sequences up; forced here): chains are row ranges, a row's arithmetic is unchanged
+    monkeypatch.setenv("CAR_CHAINS", "2")
+    t3, l3 = eng.generate(emb.cuda(), cs["n_new"], mask.cuda(), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"], return_logits=True)
+    assert eng.stats()["graph_used"]
+    assert torch.equal(t3.cpu(), t2) and torch.equal(l3.cpu(), l2)
+    monkeypatch.setenv("CAR_PHASE_OFFSET", "0")
+    t4 = eng.generate(emb.cuda(), cs["n_new"], mask.cuda(), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"])
+    assert torch.equal(t4.cpu(), t2)
     eng.close()
 
 
@@ -385,13 +393,12 @@ def test_stochastic_sampler_matches_reference_distribution(temperature, top_k, t
     eng.close()
 
 
-@pytest.mark.parametrize("single_chain", [False, True])
-def test_cfg_large_batch_chains_and_row_tiling(single_chain, monkeypatch):
-    """CFG with 2B = 144 rows laid out [cond | uncond]: nine m-blocks (ragged J = 4 tiles) in one chain — below the 192-sequence
-    threshold both parametrisations take the single-chain path today; CAR_SINGLE_CHAIN is kept so that the pair stays meaningful if the
-    threshold moves."""
-    if single_chain:
-        monkeypatch.setenv("CAR_SINGLE_CHAIN", "1")
+@pytest.mark.parametrize("chains", [1, 2])
+def test_cfg_large_batch_chains_and_row_tiling(chains, monkeypatch):
+    """CFG with 2B = 144 rows laid out [cond | uncond]: nine m-blocks (ragged J = 4 tiles) in ONE chain (what 144 rows take by default: the cut into
+    two chains starts at 192 sequences), and the same batch forced into TWO chains of [cond 36 | uncond 36] rows — the per-chain row layout, sampler
+    offsets and control-token slices of the schedule the 768-image bench runs."""
+    monkeypatch.setenv("CAR_CHAINS", str(chains))
     from controlar_amd import config as C, synth
     from controlar_amd.engine import Engine
     from oracle import controlar_oracle as O
@@ -411,7 +418,7 @@ def test_cfg_large_batch_chains_and_row_tiling(single_chain, monkeypatch):
 
 
 def _quantize_like_library(sd, cfg):
-    """Per-output-row e4m3 quantise/dequantise of the five decode linears, as engine.hip: upload_packed_fp8 does."""
+    """Per-output-row e4m3 quantise/dequantise of the five decode linears, as engine_weights.hip: dev_linear does."""
     out = dict(sd)
     names = ["output.weight"]
     for i in range(cfg.gpt.n_layer):

@@ -1,6 +1,6 @@
 """Minimal workload for rocprofv3 --pmc passes (counter collection serialises and slows every dispatch):
 XL weights, B sequences, encode + prefill + a few eager decode steps.  CAR_DEBUG_SKIP_STEPS=<n> starts the loop n positions
-late (engine.hip) so that the few profiled steps run over a long KV prefix.
+late (engine_generate.hip) so that the few profiled steps run over a long KV prefix.
 usage: pmc_workload.py B n_new [skip] [bf16|fp32]   -> decode steps profiled = n_new - 1 - skip at positions 120+skip .."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
