@@ -688,6 +688,18 @@ __global__ void mask_first_valid_kernel(const unsigned char* mask, int* jmin, in
 extern "C" void car_launch_mask_first_valid(const unsigned char* mask, int* jmin, int b, int T, hipStream_t st) {
     hipLaunchKernelGGL(mask_first_valid_kernel, dim3(b), dim3(64), 0, st, mask, jmin, T);
 }
+// out[0] = min over v[0..n): the earliest attendable text position of the whole batch (the prefill window of engine_generate.hip starts there)
+__global__ __launch_bounds__(256) void min_int_kernel(const int* v, int n, int* out) {
+    __shared__ int sm[4];
+    int m = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) m = min(m, v[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = min(min(sm[0], sm[1]), min(sm[2], sm[3]));
+}
+extern "C" void car_launch_min_int(const int* v, int n, int* out, hipStream_t st) { hipLaunchKernelGGL(min_int_kernel, dim3(1), dim3(256), 0, st, v, n, out); }
 
 // split-KV combine -> bf16 attention output (XP-packed or row-major)
 __global__ __launch_bounds__(64) void dec_attn2_combine_kernel(const float* part, bf16_t* out, int H, int nsplit, int dim, int out_packed) {
@@ -736,13 +748,14 @@ extern "C" void car_launch_dec_attn2(const Attn2P* p, int b, hipStream_t st) { c
 // =============================================================================================== prefill -> packed cache
 // k/v of the T prefix rows -> packed cache, RoPE on q,k in place (reference: gpt_t2i.py:266-277).  Same arithmetic as
 // decode.hip prefill_rope_kv_kernel; only the cache addressing differs.
-__global__ void prefill_rope_kv2_kernel(bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8) {
+__global__ void prefill_rope_kv2_kernel(bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8, int t0) {
     const long total = (long)b * Tn * H * 32;
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
-        const int pr = (int)(i % 32); const int h = (int)((i / 32) % H); const int t = (int)((i / (32L * H)) % Tn); const long bb = i / (32L * H * Tn);
-        bf16_t* row = qkv + (bb * Tn + t) * 3 * dim;
+        const int pr = (int)(i % 32); const int h = (int)((i / 32) % H); const int tw = (int)((i / (32L * H)) % Tn); const long bb = i / (32L * H * Tn);
+        bf16_t* row = qkv + (bb * Tn + tw) * 3 * dim;
+        const int t = tw + t0;                               // row tw of the prefill window is prefix position t0 + tw (cache row, rope row)
         const float cs = rope[((long)t * 32 + pr) * 2], sn = rope[((long)t * 32 + pr) * 2 + 1];
         const float q0 = bf2f(row[h * 64 + 2 * pr]), q1 = bf2f(row[h * 64 + 2 * pr + 1]);
         const float k0 = bf2f(row[dim + h * 64 + 2 * pr]), k1 = bf2f(row[dim + h * 64 + 2 * pr + 1]);
@@ -767,9 +780,9 @@ __global__ void prefill_rope_kv2_kernel(bf16_t* qkv, bf16_t* kcache, bf16_t* vca
         }
     }
 }
-extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8, hipStream_t st) {
+extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8, int t0, hipStream_t st) {
     long total = (long)b * Tn * H * 32; int g = (int)((total + 255) / 256); if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(prefill_rope_kv2_kernel, dim3(g), dim3(256), 0, st, (bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, rope, b, Tn, H, dim, SA, kv8);
+    hipLaunchKernelGGL(prefill_rope_kv2_kernel, dim3(g), dim3(256), 0, st, (bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, rope, b, Tn, H, dim, SA, kv8, t0);
 }
 
 // =============================================================================================== RMSNorm -> packed xn

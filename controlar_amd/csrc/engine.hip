@@ -93,7 +93,7 @@ extern "C" void car_destroy(car_ctx* c) {
     for (auto& kv : c->resize_cache) { (void)hipFree(kv.second.iy); (void)hipFree(kv.second.ix); if (kv.second.wy) (void)hipFree(kv.second.wy); if (kv.second.wx) (void)hipFree(kv.second.wx); }
     if (c->rope) (void)hipFree(c->rope);
     c->ctrl_in.release(); for (auto& b : c->ctrl) b.release(); c->kv.release(); for (auto& b : c->ws) b.release();
-    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->dec_parts.release(); c->rowimg.release(); c->rowunc.release(); if (c->host_flags) { (void)hipHostFree(c->host_flags); c->host_flags = nullptr; } c->canny_map.release(); c->t5_in.release(); c->t5_bias.release();
+    c->scal.release(); c->tok_out.release(); c->maskb.release(); c->maskw.release(); c->dec_parts.release(); c->rowimg.release(); c->rowunc.release(); if (c->host_flags) { (void)hipHostFree(c->host_flags); c->host_flags = nullptr; } c->canny_map.release(); c->t5_in.release(); c->t5_bias.release();
     (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); (void)hipEventDestroy(c->ev_t0); (void)hipEventDestroy(c->ev_t1); (void)hipEventDestroy(c->ev_t2);
     (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 7; ++i) { (void)hipStreamDestroy(c->streamx[i]); (void)hipEventDestroy(c->ev_joinx[i]); (void)hipEventDestroy(c->ev_phase[i]); }

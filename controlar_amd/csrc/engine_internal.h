@@ -25,7 +25,8 @@ int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStream_t st);
 int car_pick_gemm_cfg(int M, int N, int K, int epi);
 void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, int lds_pad, hipStream_t st);
 void car_launch_mask_first_valid(const unsigned char* mask, int* jmin, int b, int T, hipStream_t st);
-void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8, hipStream_t st);
+void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8, int t0, hipStream_t st);
+void car_launch_min_int(const int* v, int n, int* out, hipStream_t st);
 void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st);
 void car_launch_build_mask(const int64_t* emb_mask, const int* row_img, unsigned char* out, int b, int T, hipStream_t st);
 // canny.hip
@@ -45,7 +46,7 @@ int car_launch_flash64(const FlashP* p, int B, hipStream_t st);
 int car_launch_gemm(int mode, int amode, const GemmP* p, hipStream_t st);   // -1: GemmP::gn_part on a call that cannot take conv3_halo64_kernel (nothing launched)
 int car_conv3_halo64_ok(int mode, const GemmP* p);
 void car_launch_convert(int mode, const void* src, int src_dtype, void* dst, long n, hipStream_t st);
-void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg, hipStream_t st);
+void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, long per_src, long src_off, int use_cfg, hipStream_t st);
 void car_launch_layernorm(int mode, const void* x, const void* w, const void* b, void* y, long rows, int D, float eps, hipStream_t st);
 void car_launch_rmsnorm(int mode, const NormP* p, long rows, hipStream_t st);
 void car_launch_softmax(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, int mask_mode,
@@ -66,7 +67,7 @@ void car_launch_advance(int* pos, int* step, hipStream_t st);
 void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st);
 void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st);
 void car_launch_label_index(const int64_t* labels, const int* row_img, const int* row_unc, int num_classes, int* idx, int* err_flag, int b, hipStream_t st);
-void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, hipStream_t st);
+void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, int t0, hipStream_t st);
 void car_launch_pack_frag_f32(const void* src, void* dst, long N, long K, hipStream_t st);
 int car_launch_dec_gemm_f32_cfg(const GemmFP* p, int epi, int cfg, hipStream_t st);
 int car_pick_gemm_f32_cfg(int M, int N, int K, int epi);
@@ -115,6 +116,7 @@ struct car_ctx {
     DevBuf scal;         // device ints: pos, step, cur_tok[b]
     DevBuf tok_out;      // [B, n_new] int32
     DevBuf maskb;        // [b, T] uint8
+    DevBuf maskw;        // [b, Tv] uint8: the mask columns of the prefill window
     std::vector<int> h_rowimg;          // host staging that must outlive the async copies of a generate call
     int h_init[16] = {};
     SampleDyn h_dyn = {};

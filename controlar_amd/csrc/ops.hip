@@ -36,20 +36,22 @@ extern "C" void car_launch_convert(int mode, const void* src, int src_dtype, voi
 // text input: rows [0,B) = cond * 1 (already masked by the caller), rows [B,2B) = uncond_embedding
 // (reference generate.py:156-158)
 template <typename T>
-__global__ void build_text_kernel(const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg) {
+// `per` elements per sequence are written; they are the window [src_off, src_off + per) of the sequence's `per_src` source elements (the prefill keeps only the
+// last rows of the left-padded prefix: engine_generate.hip, "prefill window")
+__global__ void build_text_kernel(const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, long per_src, long src_off, int use_cfg) {
     const long n = (long)(use_cfg ? 2 * B : B) * per;
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         const long b = i / per, r = i - b * per;
         float v;
-        if (b < B) v = src_dtype == 1 ? bf2f(((const bf16_t*)cond)[i]) : ((const float*)cond)[i];
-        else v = ET<T>::rnd(0.f + ET<T>::ld((const T*)uncond + r));
+        if (b < B) { const long si = b * per_src + src_off + r; v = src_dtype == 1 ? bf2f(((const bf16_t*)cond)[si]) : ((const float*)cond)[si]; }
+        else v = ET<T>::rnd(0.f + ET<T>::ld((const T*)uncond + src_off + r));
         ET<T>::st((T*)dst + i, v);
     }
 }
-extern "C" void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, int use_cfg, hipStream_t st) {
-    LAUNCH_T(mode, build_text_kernel, dim3(2048), dim3(256), st, cond, src_dtype, uncond, dst, B, per, use_cfg);
+extern "C" void car_launch_build_text(int mode, const void* cond, int src_dtype, const void* uncond, void* dst, int B, long per, long per_src, long src_off, int use_cfg, hipStream_t st) {
+    LAUNCH_T(mode, build_text_kernel, dim3(2048), dim3(256), st, cond, src_dtype, uncond, dst, B, per, per_src, src_off, use_cfg);
 }
 
 // out[r, :] = table[idx[r], :]   (LabelEmbedder / tok_embeddings gather)
