@@ -140,7 +140,7 @@ int car_encode_control(car_ctx* ctx, const void* img, int32_t img_dtype, int32_t
  * Debug/teacher-forcing extras (tests): forced_tokens [B,n_new] int32 or NULL
  * (token fed back at step i is forced[i]); logits_out [B,n_new,vocab] fp32 or NULL (post-CFG logits
  * handed to sample()).
-  * Host waits: none inside the token loop.  With a text-pad mask the call reads ONE int (the earliest attendable text position of the batch) back from
+ * Host waits: none inside the token loop.  With a text-pad mask the call reads ONE int (the earliest attendable text position of the batch) back from
  * the device before it enqueues the prefill, so that the prefill runs on the valid tail of the left-padded prefix only (result-preserving: pad rows
  * influence nothing that is returned; exact-mode tokens unchanged) — it therefore waits for the producers of emb_mask on `stream`.
  */
