@@ -57,7 +57,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     // ~6 us per layer) the measured layer goes 37.0 -> 34.4 us at 2 rows, 39.4 -> 35.7 at 8, 66.5 -> 61.6 at 32; at 64 rows it is a draw (83.3 / 82.9: the
     // 960 workgroups of wqkv each repeat the row statistics) and at 128 a loss (120 / 125), so larger chains keep the norm kernels.  The first norm of layer 0
     // (token gather) and of the three control-add layers changes the stream before it is normed: those keep the prologue / kernel form.
-    const bool normx = b <= 48 && fb.ssq != nullptr && !getenv("CAR_NO_NORMX");
+    const bool normx = b <= 48 && D % 128 == 0 && D <= 2048 && fb.ssq != nullptr && !getenv("CAR_NO_NORMX");      // D/32 and D/16 partials per row: multiples of 4, at most 128 (the fold's 16-byte loads)
     int ssq_np = 0;                                                   // partials per row currently valid in fb.ssq (0: none)
     bf16_t* hc = h;                                                  // the residual stream; ping-pongs with `halt` when a control token is added
     bf16_t* halt = (bf16_t*)sb.xn + (size_t)b0 * D;                  // (the prefill's xn buffer is idle during decode)

@@ -179,3 +179,32 @@ def test_decode_gemm_tile_choice_is_valid_for_every_model_size():
                 assert I in (1, 2, 4) and J in (1, 2, 4) and w8 in (0, 1), (dim, M, N, K, epi, cfg)
                 assert N % (16 * I) == 0 and K % 32 == 0, (dim, M, N, K, epi, cfg)
                 assert epi != EPI_SWIGLU or I >= 2, (dim, M, N, K, epi, cfg)          # the (a, c) pair needs two adjacent row-blocks in one tile
+
+
+def test_exact_mode_tile_choice_and_norm_partials_are_valid_for_every_model_size():
+    """Host-side rules of round 4's decode kernels, for every LlamaGen width: (a) car_pick_gemm_f32_cfg (decode_f32.hip) hands car_launch_dec_gemm_f32_cfg a tile
+    it accepts (N % 16I == 0, K % 16 == 0, two row-blocks per tile for the SwiGLU pair) and never lets the batch change the K split (the configuration encodes
+    only the tile shape); (b) the on-the-fly RMSNorm (dec_gemm NORM == 2) folds N/32 or N/16 per-tile partials per row with 16-byte loads: that count must be
+    a multiple of 4 and at most 128 whatever tile the producer (wo / w2, car_pick_gemm_cfg) takes for chains of up to 48 rows."""
+    import ctypes as C
+    from controlar_amd import _lib
+    from controlar_amd.config import ffn_hidden_dim
+    lib = _lib.load()
+    pick32 = lib.car_pick_gemm_f32_cfg
+    pick32.restype = C.c_int; pick32.argtypes = [C.c_int] * 4
+    pick = lib.car_pick_gemm_cfg
+    pick.restype = C.c_int; pick.argtypes = [C.c_int] * 4
+    FEPI_PLAIN, FEPI_RESID, FEPI_SWIGLU, FEPI_QKV = 0, 1, 2, 3
+    for dim in (256, 768, 1024, 1280, 1536, 2048):
+        fh, V = ffn_hidden_dim(dim), 16384
+        for M in list(range(1, 18)) + [32, 36, 64, 96, 192, 384, 768]:
+            for N, K, epi in [(3 * dim, dim, FEPI_QKV), (dim, dim, FEPI_RESID), (2 * fh, dim, FEPI_SWIGLU), (dim, fh, FEPI_RESID), (V, dim, FEPI_PLAIN)]:
+                cfg = pick32(M, N, K, epi)
+                I, J = cfg // 10, cfg % 10
+                assert I in (1, 2, 4) and J in (1, 2, 4), (dim, M, N, K, cfg)
+                assert N % (16 * I) == 0 and K % 16 == 0 and (epi != FEPI_SWIGLU or I >= 2), (dim, M, N, K, cfg)
+        for M in range(1, 49):
+            for N, K in [(dim, dim), (dim, fh)]:                      # the two RESID producers of the residual stream
+                I = pick(M, N, K, 1) // 100
+                partials = N // (16 * (2 if I >= 2 else 1))
+                assert partials % 4 == 0 and 0 < partials <= 128, (dim, M, N, K, I, partials)

@@ -264,6 +264,39 @@ def test_xl_bf16_against_the_oracle_in_bf16_mode():
     eng.close()
 
 
+def test_w8a8_shallow_model_pins_the_kernel():
+    """W8A8 (e4m3 weights x e4m3 activations on v_mfma_f32_16x16x32_fp8_fp8) at XL width but THREE layers: over 36 layers the e4m3 codes of two
+    implementations decorrelate (test_fp8_decode_at_xl_dims_config5 can only grade against the model's own noise); over three, a code flip cannot compound, so
+    the HIP logits must sit as close to the oracle's W8A8 logits as the weight-only kernel sits to the oracle's weight-only logits (bf16 rounding of the same
+    three layers) plus one e4m3 rounding step's worth — a misplaced scale, a wrong operand half or a missed clamp in the fp8 path moves it by far more."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    from oracle import controlar_oracle as O
+    _threads()
+    cfg = C.xl_t2i(1024, "small", "canny")
+    cfg.gpt.n_layer = 3
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    B, H, W, n_new = 8, 512, 512, 9
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    qsd = _quantize_like_library(gsd, cfg)
+    toks_q, logits_w = O.generate(qsd, cfg, emb, n_new, mask, cfg_scale=1.0, condition=img, return_logits=True)
+    _, logits_a = O.generate(qsd, cfg, emb, n_new, mask, cfg_scale=1.0, condition=img, forced_tokens=toks_q, return_logits=True, act_fp8_decode=True)
+    dev = {}
+    for mode, ref in ((True, logits_w), ("mfma", logits_a)):
+        eng = Engine(cfg, "bf16", weights_fp8=mode); eng.load_state_dict(gsd); eng.finalize()
+        eng.encode_control(img.cuda())
+        _, logits = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=1.0, forced_tokens=toks_q, return_logits=True)
+        d = (logits.cpu()[:, 1:] - ref[:, 1:]).abs()            # decode steps only (the prefill runs on the dequantised weights in both modes)
+        dev[mode] = (float(d.max()), float(d.mean()))
+        eng.close()
+    model = (logits_a[:, 1:] - logits_w[:, 1:]).abs()
+    _record("w8a8_three_layers", weight_only_max=dev[True][0], weight_only_mean=dev[True][1], w8a8_max=dev["mfma"][0], w8a8_mean=dev["mfma"][1],
+            model_act_rounding_max=float(model.max()), model_act_rounding_mean=float(model.mean()))
+    assert dev["mfma"][1] <= 2.0 * dev[True][1] + 0.25 * float(model.mean()), (dev, float(model.mean()))
+    assert dev["mfma"][0] <= 2.0 * dev[True][0] + float(model.max()), (dev, float(model.max()))
+
+
 @pytest.mark.parametrize("size", ["tiny", "tiny+w8", "xl"])
 def test_e4m3_kv_cache_opt_in(size):
     """car_config.kv_cache_fp8 (opt-in; bf16 KV stays the default and the parity path): rotated K and V are stored as OCP e4m3 bytes, unit scale, and widened

@@ -63,5 +63,22 @@ def test_bench_config_presets(monkeypatch):
     a = args("--config", "2"); assert (a.cfg_scale, a.batch) == (4.0, 1)
     a = args("--config", "3"); assert (a.cfg_scale, a.batch, a.condition_type, a.adapter_size) == (4.0, 32, "depth", "base")
     a = args("--config", "4"); assert (a.cfg_scale, a.batch, a.image_h, a.image_w) == (4.0, 1, 768, 512)
-    a = args("--config", "5"); assert (a.batch, a.fp8_mfma, a.weights_fp8, a.adapter_size) == (8, True, True, "base")
+    a = args("--config", "5"); assert (a.batch, a.fp8_mfma, a.weights_fp8, a.adapter_size) == (8, False, True, "base")       # weight-only by default
+    a = args("--config", "5", "--fp8-mfma"); assert (a.batch, a.fp8_mfma, a.weights_fp8) == (8, True, True)                # W8A8 on request
     a = args("--gpus", "8", "--steps", "20", "--warmup", "5"); assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
+    a = args("--precision", "fp32"); assert (a.batch, a.vq_precision) == (384, "bf16")          # the tokens-exact configuration: fp32 KV of 384 sequences = 162 GB, bf16 pixels
+    a = args("--precision", "fp32", "--vq-precision", "fp32", "--batch", "192"); assert (a.batch, a.vq_precision) == (192, "fp32")
+    assert args().vq_precision == "bf16"
+
+
+def test_bench_refuses_library_switches(monkeypatch):
+    """A number measured under a CAR_* library switch (CAR_DEBUG_SKIP_STEPS starts the loop late, CAR_NO_GRAPH launches eagerly, ...) is not the benchmark."""
+    import importlib
+    import os
+    import pytest
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    bench.refuse_debug_environment()
+    monkeypatch.setenv("CAR_NO_GRAPH", "1")
+    with pytest.raises(SystemExit, match="CAR_NO_GRAPH"):
+        bench.refuse_debug_environment()
