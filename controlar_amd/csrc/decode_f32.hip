@@ -11,7 +11,7 @@
 //                  in wave order.  The slice boundaries depend on K only, never on M: every output element is the same arithmetic whatever
 //                  the batch (the exact mode is batch-invariant; tests/test_parity_gpu.py::test_exact_mode_is_batch_invariant).
 //   dec_attn_f32   single-query attention over the fp32 cache, split-KV with boundaries fixed in absolute positions (batch-invariant),
-//                  16-byte loads, 4 rows per wave instruction, 8 KiB in flight per wave.
+//                  16-byte loads, 4 rows per wave instruction, 8 waves per SIMD resident.
 //   pack_frag_f32  row-major fp32 [N][K] -> the fragment image (built once at car_finalize_weights).
 #include "car_common.h"
 #include "decode_f32_params.h"
@@ -198,7 +198,7 @@ extern "C" int car_pick_gemm_f32_cfg(int M, int N, int K, int epi) {
 // One workgroup (4 waves) per (head, sequence, split).  Split s covers the cache positions [s*AF_SPLIT, (s+1)*AF_SPLIT) ∩ [0, pos]: the
 // boundaries are absolute, so the per-split online-softmax states and their fold are the same arithmetic for any batch.  A 16-lane group
 // reads one 256-byte row with 16 bytes per lane (a wave instruction moves 1 KiB); 4 K rows + 4 V rows per lane are requested before the
-// first is used (8 KiB in flight per wave).  Wave w takes the rows j0 + 16·(4i + w) + 4u + grp of its split: 32 rows per wave per split.
+// first is used.  Wave w takes the rows j0 + 4·UNR·(4i + w) + 4u + grp of its split: AF_SPLIT / 4 rows per wave per split.
 __global__ __launch_bounds__(256) void dec_attn_f32_kernel(AttnFP p) {
     __shared__ float red[4][4][66];           // per wave, per row group: m, l, o[64]
     const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
@@ -215,8 +215,14 @@ __global__ __launch_bounds__(256) void dec_attn_f32_kernel(AttnFP p) {
 
     float m = -INFINITY, l = 0.f;
     f4 o = (f4){0.f, 0.f, 0.f, 0.f};
-    constexpr int UNR = 4;
-    for (int base = j0 + wave * 16; base < j1; base += 64) {
+    // rows in flight per lane per stream: 2 K + 2 V (4 KiB per wave).  Fewer registers beat deeper unrolling: 64 VGPRs keep 8 waves per SIMD resident
+    // (UNR 4: 100 VGPRs, 4 waves per SIMD, 374 us per layer at 384 sequences, position 631; UNR 2: 336 us = 6.27 TB/s, the chip's copy rate; UNR 1: 334;
+    // UNR 8 spills: 1270) — profiles/r04_f32_attention_split_sweep.txt
+#ifndef AF_UNR
+#define AF_UNR 2
+#endif
+    constexpr int UNR = AF_UNR;
+    for (int base = j0 + wave * (4 * UNR); base < j1; base += 16 * UNR) {
         f4 kv[UNR], vv[UNR]; bool ok[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {

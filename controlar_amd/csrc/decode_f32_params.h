@@ -24,8 +24,13 @@ struct GemmFP {
 
 // single-query attention over the valid prefix of the fp32 cache (reference: gpt_t2i.py:282-286 + the mask row of generate.py:184-193).
 // Split-KV with boundaries FIXED in absolute positions (split s = positions [s*AF_SPLIT, (s+1)*AF_SPLIT)), so a sequence decodes to the same
-// bits alone and inside any batch; the combine folds the non-empty splits in position order.
-#define AF_SPLIT 128
+// bits alone and inside any batch; the combine folds the non-empty splits in position order.  512 rows per split: measured (4-row unroll)
+// 377.8 us per layer at 384 sequences, position 631 (5.58 TB/s; 6.02 at position 1142) against 407.9 with 128 rows, 385.6 with 256, 471 with 64
+// (experiments/f32_check -DAF_SPLIT=..., profiles/r04_f32_attention_split_sweep.txt): the per-workgroup prologue (q, position) and the LDS merge amortise;
+// with the 2-row unroll that landed with it: 336 us (6.27 TB/s).
+#ifndef AF_SPLIT
+#define AF_SPLIT 512
+#endif
 struct AttnFP {
     const float* q;             // [b][H][64] rotated, pre-scaled (FEPI_QKV)
     const float* kc; const float* vc;   // [b][H][S_max][64]
