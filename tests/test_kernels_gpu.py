@@ -30,3 +30,15 @@ def test_exact_mode_kernels_against_fp64_references():
     out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout[-3000:] + out.stderr[-1000:]
     assert "BITS DIFFER" not in out.stdout and "FAIL" not in out.stdout
+
+
+def test_fp8_decode_linears_against_a_reference_on_identical_codes():
+    """dec_gemm<F8> (experiments/f8_check.hip): the e4m3 weight image pack.hip builds must hold exactly the round-to-nearest-even codes of w / (amax / 448), and
+    both fp8 linears — weight-only (codes widened to bf16 in registers) and W8A8 (activations quantised to e4m3 in registers, v_mfma_f32_16x16x32_fp8_fp8) — must
+    reproduce an fp64 product of THOSE codes (W8A8: with the activations quantised on the host by the reference rounding, ties and values beyond 448 included) to
+    the one bf16 ulp of the epilogue, for K = 1280 / 3584 and one / several m-blocks.  At whole-model level two W8A8 implementations decorrelate within three
+    layers (tests/test_configs_gpu.py); on identical inputs nothing does, so this is the check that pins the kernel."""
+    exe = _build("f8_check")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout[-3000:] + out.stderr[-1000:]
+    assert "FAIL" not in out.stdout
