@@ -105,6 +105,7 @@ extern "C" void car_destroy(car_ctx* c) {
 // logits fp32 [rows, V] (rows = 2B under CFG: cond then uncond), out int32 [B].  `step` only feeds the RNG counter / cfg_interval.
 extern "C" int car_sample_logits(car_ctx* c, const float* logits, int32_t B, int32_t V, const car_sampling* sp, int32_t step, int32_t* out, void* stream_) {
     if (!c || !logits || !sp || !out || B <= 0 || V <= 0 || V % 4 || V > 32768) { if (c) c->err = "car_sample_logits: bad arguments (V must be a multiple of 4, <= 32768)"; return -1; }
+    if (check_sticky(c)) return -1;
     hipStream_t caller = (hipStream_t)stream_, st = c->stream;
     NEED(c, c->scal, (size_t)(16 + 2 * B) * 4);
     int* stepd = (int*)c->scal.p + 1; int* cur = (int*)c->scal.p + 16;

@@ -196,6 +196,7 @@ extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype
 extern "C" int car_canny(car_ctx* c, const uint8_t* img_hwc, int32_t B, int32_t H, int32_t W, float low_threshold, float high_threshold,
                          uint8_t* edges_out, void* control_out, void* stream_) {
     if (!c) return -1;
+    if (check_sticky(c)) return -1;
     if (!img_hwc || B <= 0 || H <= 0 || W <= 0 || (!edges_out && !control_out)) FAIL(c, "car_canny: bad arguments");
     if (low_threshold > high_threshold) { const float t = low_threshold; low_threshold = high_threshold; high_threshold = t; }
     hipStream_t caller = (hipStream_t)stream_, st = c->stream;

@@ -288,7 +288,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     if (fast) { const int wg = b * Hn; while (wg * nsplit < 1024 && nsplit < 16) nsplit *= 2; }
     NEED(c, c->ws[10], (size_t)b * Hn * nsplit * 66 * 4);                     // split-KV partials
     NEED(c, c->ws[11], (size_t)B * (use_control ? n_tok : 1) * D * e);        // condition_mlp output / mlp mid
-    NEED(c, c->scal, (size_t)(16 + 2 * b + 2) * 4 + sizeof(SampleDyn) + 16 + 128);
+    // device scalars: [16 ints: (pos, step) of up to 8 chains] [cur_tok: b ints] [jmin: b ints] [jmin_min: 4 ints] [SampleDyn, 16-byte aligned]
+    NEED(c, c->scal, (size_t)(16 + 2 * b + 4) * 4 + 16 + sizeof(SampleDyn) + 16);
     NEED(c, c->rowimg, (size_t)b * 4);
     NEED(c, c->tok_out, (size_t)B * n_new * 4);
     NEED(c, c->maskb, (size_t)b * T);
@@ -305,8 +306,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     c->h_rowimg.assign(row_img.begin(), row_img.end());
     HIPCHK(c, hipMemcpyAsync(c->rowimg.p, c->h_rowimg.data(), (size_t)b * 4, hipMemcpyHostToDevice, st));
     car_launch_build_mask(emb_mask, (const int*)c->rowimg.p, (unsigned char*)c->maskb.p, b, T, st);
-    int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 16; int* jmin = cur + b;
-    SampleDyn* dyn = (SampleDyn*)(((uintptr_t)(jmin + b) + 15) & ~(uintptr_t)15);
+    int* pos = (int*)c->scal.p; int* step = pos + 1; int* cur = pos + 16; int* jmin = cur + b; int* jmin_min = jmin + b;
+    SampleDyn* dyn = (SampleDyn*)(((uintptr_t)(jmin_min + 4) + 15) & ~(uintptr_t)15);
     c->h_dyn.seed = sp->seed; c->h_dyn.temperature = sp->temperature; c->h_dyn.top_k = sp->top_k; c->h_dyn.top_p = sp->top_p;
     HIPCHK(c, hipMemcpyAsync(dyn, &c->h_dyn, sizeof(SampleDyn), hipMemcpyHostToDevice, st));
     if (emb_mask) car_launch_mask_first_valid((const unsigned char*)c->maskb.p, jmin, b, T, st);
@@ -319,10 +320,9 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     // wait of car_generate, and only when a mask is given (CAR_NO_PREFILL_WINDOW=1 keeps all T rows and no wait).
     int Tv = T, t0 = 0;
     if (emb_mask && !c2i && T > 8 && !getenv("CAR_NO_PREFILL_WINDOW")) {
-        int* dmin = jmin + b + 8 + (int)(sizeof(SampleDyn) / 4) + 4;         // scratch int behind the sampling scalars (c->scal has the room, see NEED above)
-        car_launch_min_int(jmin, b, dmin, st);
+        car_launch_min_int(jmin, b, jmin_min, st);
         int hmin = 0;
-        HIPCHK(c, hipMemcpyAsync(&hmin, dmin, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(&hmin, jmin_min, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         const int lmax = T - (hmin < 0 ? 0 : (hmin > T ? T : hmin));
         Tv = (int)rup((size_t)(lmax < 1 ? 1 : lmax), 8); if (Tv > T) Tv = T;

@@ -29,6 +29,7 @@ static int t5_bucket(int rel, int nb, int max_distance) {
 
 extern "C" int car_t5_encode(car_ctx* c, const int64_t* input_ids, const int64_t* attention_mask, int32_t B, int32_t T, void* out, void* stream_) {
     if (!c) return -1;
+    if (check_sticky(c)) return -1;
     if (!c->has_t5 || !c->finalized || !Wp(c, "t5.shared.weight")) FAIL(c, "car_t5_encode: T5 weights not loaded / finalised");
     if (!input_ids || !out || B <= 0 || T <= 0) FAIL(c, "car_t5_encode: bad arguments");
     const car_t5_config& t = c->t5;
