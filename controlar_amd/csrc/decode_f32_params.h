@@ -20,6 +20,12 @@ struct GemmFP {
     const float* rope;    // [n_pos][32][2] (cos, sin); prefix rows are zero (gpt_t2i.py:518)
     const int* pos;
     int H, S_max, dim;
+    // NX (on-the-fly RMSNorm, not with FEPI_RESID): X = the RAW residual rows, W = the image packed with the norm weight folded into its columns; the kernel
+    // accumulates each row's sum of squares and scales the folded sums by rsqrt(ssq / K + neps) before the epilogue
+    int normx; float neps;
+#ifdef CAR_STAMP
+    long long* stamp;     // experiments/f32_check -DCAR_STAMP: [workgroup][16] phase stamps of wave 0 (the product build has neither the field nor the stores)
+#endif
 };
 
 // single-query attention over the valid prefix of the fp32 cache (reference: gpt_t2i.py:282-286 + the mask row of generate.py:184-193).

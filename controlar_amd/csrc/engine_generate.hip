@@ -133,10 +133,12 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     return 0;
 }
 
-// Exact mode (decode_f32.hip): 8 kernels per layer — norm -> wqkv(+RoPE, q scale, K/V rows written at *pos) -> attention (fixed 128-position
-// splits) -> combine -> wo(+residual) -> norm -> w1|w3(+SwiGLU) -> w2(+residual); every linear runs on the exact fp32 MFMA over the fragment-packed
-// weights.  Nothing here depends on the batch except the tile shape, which does not change an output's arithmetic: a sequence decodes to the
-// same bits alone and in a batch of 384.
+// Exact mode (decode_f32.hip), round 5: 5 kernels per layer — wqkv(+on-the-fly attention_norm, RoPE, q scale, K/V rows written at *pos) -> attention (fixed
+// 512-position splits folded in one launch) -> wo(+residual) -> w1|w3(+on-the-fly ffn_norm, SwiGLU) -> w2(+residual); layer 0 (token gather) and the three
+// control-add layers put one `rmsnorm` launch in its add-only form in front.  Every linear runs on the exact fp32 MFMA over the fragment-packed weights; the
+// linears behind a norm multiply the RAW residual rows by the image that carries the norm weight in its columns and scale by rstd in the epilogue (round 4
+// ran 8 kernels per layer: two rmsnorm launches and the split-KV combine).  Nothing here depends on the batch except the tile shape, which does not change
+// an output's arithmetic: a sequence decodes to the same bits alone and in a batch of 384.
 static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b_total, int b0, int b, int S_max, int n_tok, int nsplit, bool use_ctrl,
                                float cs, const SampleP& sp_chain, int* pos, int* step, const unsigned char* maskb, hipStream_t st,
                                hipEvent_t phase_ev = nullptr, hipStream_t phase_dst = nullptr) {
@@ -151,40 +153,41 @@ static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b_total, int 
         q.W = (const float*)Wp(c, wname + "#pk32"); q.X = (const float*)X; q.ldx = ldx; q.M = b; q.N = N; q.K = K;
         const int cfg = car_pick_gemm_f32_cfg(b, N, K, epi);
         const int J = cfg % 10, Mb = (b + 15) / 16;
-        q.w_nt = (Mb + J - 1) / J == 1;
+        q.w_nt = cfg < 1000 && (Mb + J - 1) / J == 1;
         if (!q.W || car_launch_dec_gemm_f32_cfg(&q, epi, cfg, st)) bad = cfg ? cfg : -1;
         ++nk;
     };
     GemmFP z; memset(&z, 0, sizeof(z));
-    float* h = (float*)sb.h + (size_t)b0 * D; float* xn = (float*)sb.xn + (size_t)b0 * D; float* att = (float*)sb.att + (size_t)b0 * D;
+    GemmFP zn = z; zn.normx = 1; zn.neps = g.norm_eps;                  // the linears behind an RMSNorm
+    float* h = (float*)sb.h + (size_t)b0 * D; float* att = (float*)sb.att + (size_t)b0 * D;
     float* mid = (float*)sb.mid + (size_t)b0 * Fh; float* logits = sb.logits + (size_t)b0 * V; float* part = sb.part + (size_t)b0 * Hn * nsplit * 66;
     float* qbuf = (float*)sb.qkv + (size_t)b0 * D;                      // [b][H][64] rotated, pre-scaled q (the prefill's qkv buffer is idle during decode)
     for (int l = 0; l < g.n_layer; ++l) {
         const std::string L = "layers." + std::to_string(l) + ".";
         float* kc = (float*)off(c->kv.p, (size_t)(2 * l) * kv_layer + kv_off, e); float* vc = (float*)off(c->kv.p, (size_t)(2 * l + 1) * kv_layer + kv_off, e);
-        {   // token gather (layer 0), control add (layers 0, n/3, 2n/3), attention_norm
+        const bool ctrl_here = use_ctrl && l % li == 0 && l / li < 3;
+        if (l == 0 || ctrl_here) {   // token gather (layer 0), control add (layers 0, n/3, 2n/3): the residual stream changes before its norm
             NormP np; memset(&np, 0, sizeof(np));
-            np.h_in = h; np.h_out = h; np.xn = xn; np.w = Wp(c, L + "attention_norm.weight"); np.D = D; np.eps = g.norm_eps;
+            np.h_in = h; np.h_out = h; np.xn = nullptr; np.D = D; np.eps = g.norm_eps;
             if (l == 0) { np.emb = Wp(c, "tok_embeddings.weight"); np.idx = sb.cur + b0; }
-            if (use_ctrl && l % li == 0 && l / li < 3) { np.add_mode = 1; np.ctrl = off(c->ctrl[l / li].p, (size_t)b0 * n_tok * D, e); np.pos = pos; np.T = T; np.n_tok = n_tok; np.cs = cs; }
+            if (ctrl_here) { np.add_mode = 1; np.ctrl = off(c->ctrl[l / li].p, (size_t)b0 * n_tok * D, e); np.pos = pos; np.T = T; np.n_tok = n_tok; np.cs = cs; }
             car_launch_rmsnorm(mode, &np, b, st); ++nk;
         }
-        { GemmFP q = z; q.qout = qbuf; q.kc = kc; q.vc = vc; q.rope = c->rope; q.pos = pos; q.H = Hn; q.S_max = S_max; q.dim = D;
-          gemm(L + "attention.wqkv.weight", xn, D, 3 * D, D, FEPI_QKV, q); }
+        { GemmFP q = zn; q.qout = qbuf; q.kc = kc; q.vc = vc; q.rope = c->rope; q.pos = pos; q.H = Hn; q.S_max = S_max; q.dim = D;
+          gemm(L + "attention.wqkv.weight", h, D, 3 * D, D, FEPI_QKV, q); }
         if (l == 0 && phase_ev) { (void)hipEventRecord(phase_ev, st); (void)hipStreamWaitEvent(phase_dst, phase_ev, 0); }
         {
             AttnFP ap; memset(&ap, 0, sizeof(ap));
             ap.q = qbuf; ap.kc = kc; ap.vc = vc; ap.pos = pos; ap.mask = maskb ? maskb + (size_t)b0 * T : nullptr; ap.part = part; ap.out = att;
             ap.H = Hn; ap.S_max = S_max; ap.T = T; ap.dim = D; ap.nsplit_max = nsplit;
-            car_launch_dec_attn_f32(&ap, b, st); nk += 2;
+            const bool fused = (long)Hn * b >= 2048 && nsplit <= 8;
+            car_launch_dec_attn_f32_ex(&ap, b, fused ? 1 : 0, st); nk += fused ? 1 : 2;
         }
         { GemmFP q = z; q.out = h; q.ldo = D; q.R = h; gemm(L + "attention.wo.weight", att, D, D, D, FEPI_RESID, q); }
-        { NormP np; memset(&np, 0, sizeof(np)); np.h_in = h; np.xn = xn; np.w = Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps; car_launch_rmsnorm(mode, &np, b, st); ++nk; }
-        { GemmFP q = z; q.out = mid; q.ldo = Fh; gemm(L + "feed_forward.w13.weight", xn, D, 2 * Fh, D, FEPI_SWIGLU, q); }
+        { GemmFP q = zn; q.out = mid; q.ldo = Fh; gemm(L + "feed_forward.w13.weight", h, D, 2 * Fh, D, FEPI_SWIGLU, q); }
         { GemmFP q = z; q.out = h; q.ldo = D; q.R = h; gemm(L + "feed_forward.w2.weight", mid, Fh, D, Fh, FEPI_RESID, q); }
     }
-    { NormP np; memset(&np, 0, sizeof(np)); np.h_in = h; np.xn = xn; np.w = Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps; car_launch_rmsnorm(mode, &np, b, st); ++nk; }
-    { GemmFP q = z; q.out = logits; q.ldo = V; gemm("output.weight", xn, D, V, D, FEPI_PLAIN, q); }      // fp32 logits (exact mode has no bf16 round)
+    { GemmFP q = zn; q.out = logits; q.ldo = V; gemm("output.weight", h, D, V, D, FEPI_PLAIN, q); }      // final norm on the fly; fp32 logits (exact mode has no bf16 round)
     car_launch_advance(pos, step, st); ++nk;      // pos = T+i+1 consumed next step; step indexes the token being sampled
     SampleP sp = sp_chain; sp.logits = logits; sp.step_ptr = step; car_launch_sample_greedy(&sp, st); ++nk;
     c->n_dec_kernels = nk;

@@ -68,10 +68,11 @@ void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void*
 void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st);
 void car_launch_label_index(const int64_t* labels, const int* row_img, const int* row_unc, int num_classes, int* idx, int* err_flag, int b, hipStream_t st);
 void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int S_max, int t0, hipStream_t st);
-void car_launch_pack_frag_f32(const void* src, void* dst, long N, long K, hipStream_t st);
+void car_launch_pack_frag_f32(const void* src, void* dst, long N, long K, const void* colscale, hipStream_t st);
 int car_launch_dec_gemm_f32_cfg(const GemmFP* p, int epi, int cfg, hipStream_t st);
 int car_pick_gemm_f32_cfg(int M, int N, int K, int epi);
 void car_launch_dec_attn_f32(const AttnFP* p, int b, hipStream_t st);
+void car_launch_dec_attn_f32_ex(const AttnFP* p, int b, int fused, hipStream_t st);
 }
 
 

@@ -20,8 +20,13 @@ static int upload(car_ctx* c, const std::string& name, const std::vector<float>&
     auto it = c->w.find(name);
     if (it != c->w.end() && it->second.p) (void)hipFree(it->second.p);
     c->w[name] = t;
-    auto pk = c->w.find(name + "#pk32");       // a re-loaded tensor invalidates its exact-mode fragment image (rebuilt by car_finalize_weights)
-    if (pk != c->w.end()) { if (pk->second.p) (void)hipFree(pk->second.p); c->w.erase(pk); }
+    // a re-loaded tensor invalidates its exact-mode fragment image (rebuilt by car_finalize_weights); a re-loaded RMSNorm weight invalidates the image of the
+    // linear it is folded into (decode_f32.hip NX: wqkv <- attention_norm, w1|w3 <- ffn_norm, output <- norm)
+    std::vector<std::string> stale = {name + "#pk32"};
+    auto dep = [&](const char* sfx, const char* lin) { const size_t n = strlen(sfx); if (name.size() >= n && name.compare(name.size() - n, n, sfx) == 0) stale.push_back(name.substr(0, name.size() - n) + lin + "#pk32"); };
+    dep("attention_norm.weight", "attention.wqkv.weight"); dep("ffn_norm.weight", "feed_forward.w13.weight");
+    if (name == "norm.weight") stale.push_back("output.weight#pk32");
+    for (auto& sname : stale) { auto pk = c->w.find(sname); if (pk != c->w.end()) { if (pk->second.p) (void)hipFree(pk->second.p); c->w.erase(pk); } }
     return 0;
 }
 
@@ -364,7 +369,14 @@ extern "C" int car_finalize_weights(car_ctx* c) {
             auto it = c->w.find(r + "#pk32");
             if (it != c->w.end() && it->second.p && it->second.bytes == src.bytes) continue;
             if (ensure_w(c, r + "#pk32", src.bytes, src.shape, src.numel)) return -1;
-            car_launch_pack_frag_f32(c->w[r].p, c->w[r + "#pk32"].p, src.shape[0], src.shape[1], 0);
+            // the linears behind an RMSNorm get the norm weight folded into their columns: their decode GEMM multiplies the raw residual rows and applies
+            // rstd in its epilogue (decode_f32.hip NX).  The row-major tensor (prefill operand) stays as loaded.
+            const void* fold = nullptr;
+            auto folded = [&](const char* lin, const char* nrm) { const size_t n = strlen(lin); if (r.size() >= n && r.compare(r.size() - n, n, lin) == 0) fold = Wp(c, r.substr(0, r.size() - n) + nrm); };
+            folded("attention.wqkv.weight", "attention_norm.weight"); folded("feed_forward.w13.weight", "ffn_norm.weight");
+            if (r == "output.weight") fold = Wp(c, "norm.weight");
+            if ((r == "output.weight" || r.find("wqkv") != std::string::npos || r.find("w13") != std::string::npos) && !fold) FAIL(c, "%s: the RMSNorm weight in front of it is missing", r.c_str());
+            car_launch_pack_frag_f32(c->w[r].p, c->w[r + "#pk32"].p, src.shape[0], src.shape[1], fold, 0);
         }
         hipError_t e2 = hipStreamSynchronize(0); if (e2 == hipSuccess) e2 = hipGetLastError();
         if (e2 != hipSuccess) FAIL(c, "car_finalize_weights: fp32 fragment packing failed: %s", hipGetErrorString(e2));

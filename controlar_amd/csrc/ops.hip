@@ -154,6 +154,11 @@ __global__ __launch_bounds__(1024) void rmsnorm_kernel(NormP p) {
             for (int e = 0; e < 4; ++e) { val[q][e] = v[e]; ss += v[e] * v[e]; }
         }
     }
+    if (!p.xn) {        // gather / control-add only (exact-mode decode, round 5: the norm itself runs inside the consuming GEMM, decode_f32.hip NX)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int gi = threadIdx.x + q * blockDim.x; if (gi < ng && p.h_out) st4<T>((T*)p.h_out + r * D + gi * 4, val[q]); }
+        return;
+    }
     const float rstd = rsqrtf(block_sum(ss, sm) / D + p.eps);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -182,9 +182,9 @@ def test_decode_gemm_tile_choice_is_valid_for_every_model_size():
 
 
 def test_exact_mode_tile_choice_and_norm_partials_are_valid_for_every_model_size():
-    """Host-side rules of round 4's decode kernels, for every LlamaGen width: (a) car_pick_gemm_f32_cfg (decode_f32.hip) hands car_launch_dec_gemm_f32_cfg a tile
-    it accepts (N % 16I == 0, K % 16 == 0, two row-blocks per tile for the SwiGLU pair) and never lets the batch change the K split (the configuration encodes
-    only the tile shape); (b) the on-the-fly RMSNorm (dec_gemm NORM == 2) folds N/32 or N/16 per-tile partials per row with 16-byte loads: that count must be
+    """Host-side rules of the exact-mode decode kernels, for every LlamaGen width: (a) car_pick_gemm_f32_cfg (decode_f32.hip) hands car_launch_dec_gemm_f32_cfg a tile
+    it accepts (register kernel: N % 16I == 0, K % 16 == 0, two row-blocks per tile for the SwiGLU pair; tiled kernel: K % 128 == 0, N % 32WN == 0) and never lets
+    the batch change an output's arithmetic (every configuration computes the canonical 8-slice tree); (b) the on-the-fly RMSNorm (dec_gemm NORM == 2) folds N/32 or N/16 per-tile partials per row with 16-byte loads: that count must be
     a multiple of 4 and at most 128 whatever tile the producer (wo / w2, car_pick_gemm_cfg) takes for chains of up to 48 rows."""
     import ctypes as C
     from controlar_amd import _lib
@@ -200,6 +200,11 @@ def test_exact_mode_tile_choice_and_norm_partials_are_valid_for_every_model_size
         for M in list(range(1, 18)) + [32, 36, 64, 96, 192, 384, 768]:
             for N, K, epi in [(3 * dim, dim, FEPI_QKV), (dim, dim, FEPI_RESID), (2 * fh, dim, FEPI_SWIGLU), (dim, fh, FEPI_RESID), (V, dim, FEPI_PLAIN)]:
                 cfg = pick32(M, N, K, epi)
+                if cfg >= 1000:      # round 5: the LDS-tiled kernel, cfg = 1000 + 100 WN + 10 WM + KG; it needs 8 equal K slices and whole 32·WN-row tiles
+                    WN, WM, KG = (cfg - 1000) // 100, (cfg // 10) % 10, cfg % 10
+                    assert cfg in (1221, 1212, 1214), (dim, M, N, K, cfg)       # the configurations the product library instantiates
+                    assert K % 128 == 0 and N % (32 * WN) == 0 and KG in (1, 2, 4), (dim, M, N, K, cfg)
+                    continue
                 I, J = cfg // 10, cfg % 10
                 assert I in (1, 2, 4) and J in (1, 2, 4), (dim, M, N, K, cfg)
                 assert N % (16 * I) == 0 and K % 16 == 0 and (epi != FEPI_SWIGLU or I >= 2), (dim, M, N, K, cfg)
