@@ -11,6 +11,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcontrolar_hip.so")
+# The same sources compiled with -DCAR_DEV_KNOBS (csrc/build.sh): the A/B and profiling switches behind CAR_* environment variables exist ONLY there.
+# Loaded when CONTROLAR_DEV_LIB=1 is in the environment or on request (`load(dev=True)`, `Engine(..., dev=True)`: tools/, the schedule-invariance tests).
+DEV_LIB_PATH = os.path.join(_HERE, "csrc", "libcontrolar_hip_dev.so")
 
 CAR_ABI_VERSION = 1
 CAR_F32, CAR_BF16 = 0, 1
@@ -85,21 +88,31 @@ SYMBOLS = {
 }
 
 _lib = None
+_lib_dev = None
 
 
-def load() -> C.CDLL:
-    """Loads the HIP library; raises (never falls back) when it is absent or incomplete."""
-    global _lib
-    if _lib is not None:
+def load(dev=None) -> C.CDLL:
+    """Loads the HIP library; raises (never falls back) when it is absent or incomplete.  `dev`: the development build with the CAR_* switches
+    (default: only when CONTROLAR_DEV_LIB=1)."""
+    global _lib, _lib_dev
+    if dev is None:
+        dev = os.environ.get("CONTROLAR_DEV_LIB") == "1"
+    if dev and _lib_dev is not None:
+        return _lib_dev
+    if not dev and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} not found — build it with `python __graft_entry__.py build` "
+    path = DEV_LIB_PATH if dev else LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found — build it with `python __graft_entry__.py build` "
                           "(controlar_amd has no CPU or PyTorch fallback)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
     if lib.car_abi_version() != CAR_ABI_VERSION:
         raise ImportError("libcontrolar_hip.so ABI version mismatch")
+    if dev:
+        _lib_dev = lib
+        return lib
     _lib = lib
     return lib

@@ -6,6 +6,17 @@
 
 typedef uint16_t bf16_t;   // raw bf16 bits
 
+// A/B and profiling switches (CAR_* environment variables: DESIGN.md §4, tools/*_sweep.py, experiments/) exist only in the DEVELOPMENT build of the library
+// (libcontrolar_hip_dev.so, compiled with -DCAR_DEV_KNOBS by build.sh).  The shipped libcontrolar_hip.so contains neither the getenv calls nor the names.
+#include <stdlib.h>
+#ifdef CAR_DEV_KNOBS
+extern "C" int g_car_knob_hits;      // switches actually found set since the counter was last cleared (car_stats.dev_knobs_active; defined in engine.hip)
+static inline const char* car_knob_get(const char* name) { const char* v = getenv(name); if (v) __atomic_fetch_add(&g_car_knob_hits, 1, __ATOMIC_RELAXED); return v; }
+#define CAR_KNOB(name) car_knob_get(name)
+#else
+#define CAR_KNOB(name) ((const char*)nullptr)
+#endif
+
 __host__ __device__ inline float bf2f(bf16_t v) {
     union { uint32_t u; float f; } c; c.u = ((uint32_t)v) << 16; return c.f;
 }

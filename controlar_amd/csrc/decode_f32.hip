@@ -104,6 +104,7 @@ __device__ inline void f32_epilogue(const GemmFP& p, const f4 (&v)[IW], int rbA,
 template <int I, int J, int EPI, int NX>
 __global__ __launch_bounds__(F32_WAVES * 64) void dec_gemm_f32_kernel(GemmFP p) {
     extern __shared__ __attribute__((aligned(16))) float red_all[];   // [8 waves][I*J][64] f4 (+ NX: [8 waves][J][16] slice sums of squares)
+    if (p.w_nt & 2) __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
     const int nkb = p.K >> 4, Mb = (p.M + 15) >> 4, MT = (Mb + J - 1) / J;
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of tiles so that the M tiles
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(F32_WAVES * 64) void dec_gemm_f32_kernel(GemmFP p) 
     const f4 z4 = (f4){0.f, 0.f, 0.f, 0.f};
     auto load = [&](f4 (&w)[I], f4 (&x)[J], int kb) {
 #pragma unroll
-        for (int i = 0; i < I; ++i) { const f4* a = wp + ((long)i * nkb + kb) * 64; w[i] = p.w_nt ? __builtin_nontemporal_load(a) : *a; }
+        for (int i = 0; i < I; ++i) { const f4* a = wp + ((long)i * nkb + kb) * 64; w[i] = (p.w_nt & 1) ? __builtin_nontemporal_load(a) : *a; }
 #pragma unroll
         for (int j = 0; j < J; ++j) { x[j] = z4; if (xok[j]) x[j] = *(const f4*)(xr[j] + kb * 16); }
     };
@@ -220,6 +221,7 @@ template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt v
 template <int WN, int WM, int KG, int SK, int NST, int EPI, int NX>
 __global__ __launch_bounds__(WN * WM * KG * 64, (WN * WM * KG == 4 ? 3 : (KG == 1 ? 2 : 4))) void dec_gemm_f32t_kernel(GemmFP p) {
     extern __shared__ __attribute__((aligned(16))) float ring_all[];
+    if (p.w_nt & 2) __builtin_amdgcn_s_setprio(3);
     constexpr int NW = WN * WM, RBW = 2 * WN, MBW = 2 * WM, CHK = RBW + MBW, CH = CHK * SK, SLG = 8 / KG;
     constexpr int PW = RBW * SK / NW, PX = MBW * SK / NW, CPW = PW + PX;          // W and X pieces per wave per stage
     static_assert((RBW * SK) % NW == 0 && (MBW * SK) % NW == 0 && (KG == 1 || KG == 2 || KG == 4 || KG == 8) && NST >= 2, "dec_gemm_f32t configuration");
@@ -566,16 +568,23 @@ __global__ __launch_bounds__(64) void dec_attn_f32_combine_kernel(AttnFP p) {
     p.out[(long)b * p.dim + h * 64 + d] = O / L;
 }
 
-// One workgroup per (head, sequence) walks ALL splits of the sequence and folds them itself: the per-split arithmetic and the fold over splits are the
-// statements of the two kernels above (the same fixed order, hence the same bits — experiments/f32_check compares them), without the round trip of the
-// partials through HBM and without the second launch.  Used when (head, sequence) pairs alone fill the chip.
-__global__ __launch_bounds__(256) void dec_attn_f32_fused_kernel(AttnFP p) {
-    __shared__ float red[4][4][66];           // per wave, per row group: m, l, o[64]
-    __shared__ float spl[8][66];              // per split: m, l, o[64]
-    const int h = blockIdx.x, b = blockIdx.y;
+// NI (head, sequence) items per workgroup, 4 waves each, walk ALL splits of their sequence and fold them themselves: the per-split arithmetic and the fold over
+// splits are the statements of the two kernels above (the same fixed order, hence the same bits — experiments/f32_check compares them), without the round trip
+// of the partials through HBM and without the second launch.  Used when (head, sequence) pairs alone fill the chip.
+// NI = 3 (768-thread workgroups) is the form for steps with several chains: the 32-wave limit of a CU admits two such workgroups = 24 waves, so EIGHT WAVE SLOTS
+// PER CU STAY FREE for the other chain's linears, which otherwise cannot place a workgroup until the attention grid drains (profiles/r05_exact_b384_timeline.txt:
+// w2 of the other chain "ran" 169 us beside a 181-us attention and finished with its tail).  Same bytes in flight per CU as 4-wave workgroups at 6 per CU.
+template <int NI>
+__global__ __launch_bounds__(256 * NI) void dec_attn_f32_fused_kernel(AttnFP p, int n_items) {
+    extern __shared__ float occupancy_pad[];  // never touched: the launcher sizes it to cap the workgroups per CU (form 4)
+    __shared__ float red[NI][4][4][66];       // per item: per wave, per row group: m, l, o[64]
+    __shared__ float spl[NI][8][66];          // per item, per split: m, l, o[64]
+    const int tid = threadIdx.x, it = tid >> 8, t256 = tid & 255, lane = tid & 63, wave = t256 >> 6, grp = lane >> 4, sub = lane & 15;
+    const int item = blockIdx.x * NI + it;
+    const bool live = item < n_items;         // a dead item (grid tail) loads nothing but keeps the barrier count
+    const int b = live ? item / p.H : 0, h = live ? item - b * p.H : 0;
     const int pos = *p.pos;
     const int ns = pos / AF_SPLIT + 1;        // <= nsplit_max <= 8 (checked by the launcher)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
     const long sbase = ((long)b * p.H + h) * p.S_max * 64;
     const float* kc = p.kc + sbase + sub * 4;
     const float* vc = p.vc + sbase + sub * 4;
@@ -583,7 +592,7 @@ __global__ __launch_bounds__(256) void dec_attn_f32_fused_kernel(AttnFP p) {
     const unsigned char* mk = p.mask ? p.mask + (long)b * p.T : nullptr;
     constexpr int UNR = AF_UNR;
     for (int split = 0; split < ns; ++split) {
-        const int j0 = split * AF_SPLIT, j1 = min(pos + 1, j0 + AF_SPLIT);
+        const int j0 = split * AF_SPLIT, j1 = live ? min(pos + 1, j0 + AF_SPLIT) : j0;
         float m = -INFINITY, l = 0.f;
         f4 o = (f4){0.f, 0.f, 0.f, 0.f};
         for (int base = j0 + wave * (4 * UNR); base < j1; base += 16 * UNR) {
@@ -608,39 +617,50 @@ __global__ __launch_bounds__(256) void dec_attn_f32_fused_kernel(AttnFP p) {
                 }
             }
         }
-        if (sub == 0) { red[wave][grp][0] = m; red[wave][grp][1] = l; }
-        *(f4*)&red[wave][grp][2 + sub * 4] = o;
+        if (sub == 0) { red[it][wave][grp][0] = m; red[it][wave][grp][1] = l; }
+        *(f4*)&red[it][wave][grp][2 + sub * 4] = o;
         __syncthreads();
-        if (tid < 64) {
+        if (t256 < 64) {
             float M = -INFINITY;
-            for (int w = 0; w < 4; ++w) for (int g = 0; g < 4; ++g) M = fmaxf(M, red[w][g][0]);
+            for (int w = 0; w < 4; ++w) for (int g = 0; g < 4; ++g) M = fmaxf(M, red[it][w][g][0]);
             float L = 0.f, O = 0.f;
             for (int w = 0; w < 4; ++w) for (int g = 0; g < 4; ++g) {
-                const float mm = red[w][g][0];
-                if (mm > -INFINITY) { const float a = expf(mm - M); L += red[w][g][1] * a; O += red[w][g][2 + tid] * a; }
+                const float mm = red[it][w][g][0];
+                if (mm > -INFINITY) { const float a = expf(mm - M); L += red[it][w][g][1] * a; O += red[it][w][g][2 + t256] * a; }
             }
-            if (tid == 0) { spl[split][0] = M; spl[split][1] = L; }
-            spl[split][2 + tid] = O;
+            if (t256 == 0) { spl[it][split][0] = M; spl[it][split][1] = L; }
+            spl[it][split][2 + t256] = O;
         }
         __syncthreads();                      // `red` is rewritten by the next split
     }
-    if (tid < 64) {
+    if (t256 < 64 && live) {
         float M = -INFINITY;
-        for (int s = 0; s < ns; ++s) M = fmaxf(M, spl[s][0]);
+        for (int s = 0; s < ns; ++s) M = fmaxf(M, spl[it][s][0]);
         float L = 0.f, O = 0.f;
         for (int s = 0; s < ns; ++s) {
-            const float mm = spl[s][0];
-            if (mm > -INFINITY) { const float a = expf(mm - M); L += spl[s][1] * a; O += spl[s][2 + tid] * a; }
+            const float mm = spl[it][s][0];
+            if (mm > -INFINITY) { const float a = expf(mm - M); L += spl[it][s][1] * a; O += spl[it][s][2 + t256] * a; }
         }
-        p.out[(long)b * p.dim + h * 64 + tid] = O / L;
+        p.out[(long)b * p.dim + h * 64 + t256] = O / L;
     }
 }
 
-// `fused`: 1 = one launch (no partials), 0 = split kernel + combine, -1 = choose: the fused form when (head, sequence) pairs alone give every CU
-// >= 8 workgroups (2048 on MI355X), else the split form (3 x the workgroups for a handful of sequences)
+// `fused`: 0 = split kernel + combine; 1 = one launch, 4-wave workgroups; 3 = one launch, 12-wave workgroups of three (head, sequence) items (leaves a
+// quarter of every CU's wave slots to concurrent kernels: steps with several chains); -1 = choose 1 when (head, sequence) pairs alone give every CU
+// >= 8 workgroups (2048 on MI355X), else 0 (3 x the workgroups for a handful of sequences).  Every form yields the same bits.
 extern "C" void car_launch_dec_attn_f32_ex(const AttnFP* p, int b, int fused, hipStream_t st) {
-    if (fused < 0) fused = (long)p->H * b >= 2048;
-    if (fused && p->nsplit_max <= 8) { hipLaunchKernelGGL(dec_attn_f32_fused_kernel, dim3(p->H, b), dim3(256), 0, st, *p); return; }
+    const int items = p->H * b;
+    if (fused < 0) fused = items >= 2048;
+    if (fused && p->nsplit_max <= 8) {
+        if (fused == 3) hipLaunchKernelGGL(dec_attn_f32_fused_kernel<3>, dim3((items + 2) / 3), dim3(768), 0, st, *p, items);
+        else if (fused == 4) {      // 16-wave workgroups, ONE per CU (56 KiB of padding on top of 25 KiB): half of every CU's wave slots stay free
+            static bool attr_set[16] = {}; int dev = 0; (void)hipGetDevice(&dev);
+            if (dev >= 0 && dev < 16 && !attr_set[dev]) { (void)hipFuncSetAttribute((const void*)dec_attn_f32_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 57344); attr_set[dev] = true; }
+            hipLaunchKernelGGL(dec_attn_f32_fused_kernel<4>, dim3((items + 3) / 4), dim3(1024), 57344, st, *p, items);
+        }
+        else hipLaunchKernelGGL(dec_attn_f32_fused_kernel<1>, dim3(items), dim3(256), 0, st, *p, items);
+        return;
+    }
     hipLaunchKernelGGL(dec_attn_f32_kernel, dim3(p->H, b, p->nsplit_max), dim3(256), 0, st, *p);
     hipLaunchKernelGGL(dec_attn_f32_combine_kernel, dim3(p->H, b), dim3(64), 0, st, *p);
 }

@@ -11,7 +11,7 @@ struct GemmFP {
     const float* X;       // row-major [M][ldx] fp32 (L2-resident activations, read in place)
     long ldx;
     int M, N, K;
-    int w_nt;             // stream W with the non-temporal policy (one M tile per weight row-block: every byte is used once)
+    int w_nt;             // bit 0: stream W with the non-temporal policy (one M tile per weight row-block: every byte is used once); bit 1: raised wave priority (s_setprio 3)
     // FEPI_PLAIN: out[m][n] (ld = ldo).  FEPI_RESID: out[m][n] = R[m][n] + acc (R may alias out).  FEPI_SWIGLU: out[m][hid] = silu(a) * c, ld = ldo
     float* out; long ldo; const float* R;
     // FEPI_QKV (gpt_t2i.py:264-277, :522-532, :227-235): 2-D RoPE on q and k, q pre-scaled by head_dim^-0.5, K / V rows written at *pos

@@ -7,6 +7,9 @@
 // own stream (graph capture is illegal on the legacy default stream torch uses by default) and
 // fenced against the caller's stream with events — no host synchronisation inside the token loop.
 #include "engine_internal.h"
+#ifdef CAR_DEV_KNOBS
+extern "C" { int g_car_knob_hits = 0; }
+#endif
 
 static thread_local std::string g_create_err;
 unsigned long long g_alloc_gen = 0;
@@ -149,9 +152,8 @@ extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
         c->stats.decode_algo_bytes = (int64_t)(c->st_wbytes * c->st_nsteps + kvb);
     }
     {   // the library's A/B / profiling switches are CAR_* environment variables: report how many are set (0 = the shipped schedule)
-        extern char** environ;
-        int n = 0;
-        for (char** e = environ; e && *e; ++e) if (!strncmp(*e, "CAR_", 4)) ++n;
+        // switches the library actually read as set while it enqueued the last generate (latched there): always 0 in the shipped build, which has no switches
+        const int n = c->knob_hits;
         c->stats.dev_knobs_active = n;
     }
     *out = c->stats;

@@ -49,7 +49,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     // 8 rows 47.8 -> 37.4 with 8-wave tiles (one row of the prologue norm per wave); from 12 rows up the fused prologue (every workgroup
     // repeats the norm of all rows) no longer wins (44.1 either way at 12, 50.1 vs 49.4 at 16) and the separate norm kernels stay.
     // The floor of this structure is the kernel boundary itself: 5 EMPTY kernels per layer cost 8.3 us.
-    const bool fuse_norm = b <= 8 && D <= 2048 && !getenv("CAR_NO_SMALL_FUSE");
+    const bool fuse_norm = b <= 8 && D <= 2048 && !CAR_KNOB("CAR_NO_SMALL_FUSE");
     // chains of up to 48 rows (round 4, experiments/lat_probe: profiles/r04_lat_probe_v5_*): the RMSNorm in front of wqkv / w1|w3 / output is applied ON THE FLY.
     // The RESID linear that produced the residual stream (wo, w2) leaves each row's sum of squares as per-tile partials; the consumer folds them into rstd
     // and normalises the bf16 residual rows it loads as its X operand in registers (dec_gemm NORM == 2).  Against the prologue form (<= 8 rows: a barrier-
@@ -57,7 +57,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     // ~6 us per layer) the measured layer goes 37.0 -> 34.4 us at 2 rows, 39.4 -> 35.7 at 8, 66.5 -> 61.6 at 32; at 64 rows it is a draw (83.3 / 82.9: the
     // 960 workgroups of wqkv each repeat the row statistics) and at 128 a loss (120 / 125), so larger chains keep the norm kernels.  The first norm of layer 0
     // (token gather) and of the three control-add layers changes the stream before it is normed: those keep the prologue / kernel form.
-    const bool normx = b <= 48 && D % 128 == 0 && D <= 2048 && fb.ssq != nullptr && !getenv("CAR_NO_NORMX");      // D/32 and D/16 partials per row: multiples of 4, at most 128 (the fold's 16-byte loads)
+    const bool normx = b <= 48 && D % 128 == 0 && D <= 2048 && fb.ssq != nullptr && !CAR_KNOB("CAR_NO_NORMX");      // D/32 and D/16 partials per row: multiples of 4, at most 128 (the fold's 16-byte loads)
     int ssq_np = 0;                                                   // partials per row currently valid in fb.ssq (0: none)
     bf16_t* hc = h;                                                  // the residual stream; ping-pongs with `halt` when a control token is added
     bf16_t* halt = (bf16_t*)sb.xn + (size_t)b0 * D;                  // (the prefill's xn buffer is idle during decode)
@@ -149,11 +149,12 @@ static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b_total, int 
     const int D = g.dim, Hn = g.n_head, Fh = g.ffn_hidden, li = g.n_layer / 3, V = g.vocab_size, T = g.cls_token_num;
     const size_t kv_layer = (size_t)b_total * Hn * S_max * 64, kv_off = (size_t)b0 * Hn * S_max * 64;
     int nk = 0, bad = 0;
+    bool lin_prio = false; { const char* ev = CAR_KNOB("CAR_LINEAR_PRIO"); if (ev) lin_prio = atoi(ev) != 0; }
     auto gemm = [&](const std::string& wname, const void* X, long ldx, int N, int K, int epi, GemmFP q) {
         q.W = (const float*)Wp(c, wname + "#pk32"); q.X = (const float*)X; q.ldx = ldx; q.M = b; q.N = N; q.K = K;
         const int cfg = car_pick_gemm_f32_cfg(b, N, K, epi);
         const int J = cfg % 10, Mb = (b + 15) / 16;
-        q.w_nt = cfg < 1000 && (Mb + J - 1) / J == 1;
+        q.w_nt = (cfg < 1000 && (Mb + J - 1) / J == 1 ? 1 : 0) | (lin_prio ? 2 : 0);
         if (!q.W || car_launch_dec_gemm_f32_cfg(&q, epi, cfg, st)) bad = cfg ? cfg : -1;
         ++nk;
     };
@@ -180,8 +181,11 @@ static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b_total, int 
             AttnFP ap; memset(&ap, 0, sizeof(ap));
             ap.q = qbuf; ap.kc = kc; ap.vc = vc; ap.pos = pos; ap.mask = maskb ? maskb + (size_t)b0 * T : nullptr; ap.part = part; ap.out = att;
             ap.H = Hn; ap.S_max = S_max; ap.T = T; ap.dim = D; ap.nsplit_max = nsplit;
-            const bool fused = (long)Hn * b >= 2048 && nsplit <= 8;
-            car_launch_dec_attn_f32_ex(&ap, b, fused ? 1 : 0, st); nk += fused ? 1 : 2;
+            const bool fused = (long)Hn * b_total >= 2048 && nsplit <= 8;
+            // several chains: 12-wave attention workgroups (two per CU = 24 of its 32 wave slots), so that the other chain's linears find room beside it
+            int form = fused ? (b < b_total ? 3 : 1) : 0;
+            { const char* ev = CAR_KNOB("CAR_ATTN_F32_FORM"); if (ev && fused) form = atoi(ev); }
+            car_launch_dec_attn_f32_ex(&ap, b, form, st); nk += fused ? 1 : 2;
         }
         { GemmFP q = z; q.out = h; q.ldo = D; q.R = h; gemm(L + "attention.wo.weight", att, D, D, D, FEPI_RESID, q); }
         { GemmFP q = zn; q.out = mid; q.ldo = Fh; gemm(L + "feed_forward.w13.weight", h, D, 2 * Fh, D, FEPI_SWIGLU, q); }
@@ -222,6 +226,10 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
                          int32_t use_control, const car_sampling* sp, int32_t* out_tokens, const int32_t* forced_tokens,
                          float* logits_out, void* stream_) {
     if (check_sticky(c)) return -1;
+#ifdef CAR_DEV_KNOBS
+    g_car_knob_hits = 0;      // every switch read below (and by the kernels' launchers) counts into car_stats.dev_knobs_active of this call
+    struct KnobLatch { car_ctx* c; ~KnobLatch() { c->knob_hits = g_car_knob_hits; } } knob_latch{c};
+#endif
     if (!c->finalized) FAIL(c, "car_generate: call car_finalize_weights first");
     if (!c->has_gpt) FAIL(c, "car_generate: this context holds VQ weights only");
     if (!sp || !out_tokens || B <= 0 || n_new <= 0) FAIL(c, "car_generate: bad arguments");
@@ -252,8 +260,12 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     // (exact mode, round 4: the same cut — its linears are bound by the fp32 matrix pipe and its attention by HBM, so the two chains overlap DIFFERENT resources;
     //  the rows of a chain are computed exactly as in any other batch, so the cut does not touch the mode's batch invariance)
     int NG = b >= 192 ? 2 : 1;
-    { const char* ev = getenv("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 8 && B / v >= 2) NG = v; } }
-    if (getenv("CAR_SINGLE_CHAIN") || NG > B) NG = 1;
+    // exact mode, round 5 (profiles/r05_exact_probe_*.txt, 384 sequences, mean position, ms per step): 1 chain 18.50, 2 chains 18.10, 3 chains 17.42, 4 chains
+    // 19.24, 6 chains 21.96.  The attention runs as 12-wave workgroups (decode_f32.hip: 24 of a CU's 32 wave slots), so the other chains' linears are resident
+    // beside it; a chain's four linears have to finish while the OTHER chains stream their KV, and with three chains that window is two attentions long.
+    if (!fast && b >= 288) NG = 3;
+    { const char* ev = CAR_KNOB("CAR_CHAINS"); if (ev) { int v = atoi(ev); if (v >= 1 && v <= 8 && B / v >= 2) NG = v; } }
+    if (CAR_KNOB("CAR_SINGLE_CHAIN") || NG > B) NG = 1;
     int img0[9];
     for (int gi = 0; gi <= NG; ++gi) img0[gi] = (int)((long)B * gi / NG);
     std::vector<int> row_img((size_t)b), row_unc((size_t)b);
@@ -322,7 +334,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     // exact-mode tokens stay bit-identical.  Cost: ONE 4-byte device-to-host read of the batch minimum of `jmin` before the prefill is enqueued — the only host
     // wait of car_generate, and only when a mask is given (CAR_NO_PREFILL_WINDOW=1 keeps all T rows and no wait).
     int Tv = T, t0 = 0;
-    if (emb_mask && !c2i && T > 8 && !getenv("CAR_NO_PREFILL_WINDOW")) {
+    if (emb_mask && !c2i && T > 8 && !CAR_KNOB("CAR_NO_PREFILL_WINDOW")) {
         car_launch_min_int(jmin, b, jmin_min, st);
         int hmin = 0;
         HIPCHK(c, hipMemcpyAsync(&hmin, jmin_min, 4, hipMemcpyDeviceToHost, st));
@@ -342,7 +354,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     {
         // profiling aid (tools/pmc_workload.py): start the decode loop `skip` positions late so that a handful of steps under
         // counter collection see a long KV prefix.  The skipped cache rows hold zeros / stale rows: tokens are meaningless.
-        int skip = 0; { const char* ev = getenv("CAR_DEBUG_SKIP_STEPS"); if (ev) { skip = atoi(ev); if (skip < 0 || skip > n_new - 2) skip = 0; } }
+        int skip = 0; { const char* ev = CAR_KNOB("CAR_DEBUG_SKIP_STEPS"); if (ev) { skip = atoi(ev); if (skip < 0 || skip > n_new - 2) skip = 0; } }
         c->dbg_skip = skip;
         for (int i = 0; i < 8; ++i) { c->h_init[2 * i] = T + skip; c->h_init[2 * i + 1] = skip; }    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
         HIPCHK(c, hipMemcpyAsync(pos, c->h_init, 64, hipMemcpyHostToDevice, st));
@@ -468,15 +480,15 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             // a handful of sequences (<= 240 (sequence, head) pairs = 12 XL sequences): ONE launch of 16-wave workgroups instead of split-KV + combine —
             // one dependent kernel less per layer.  tools/small_ab.py on MI355X (XL, 1024 tokens, ms per step, same process): 2 rows 1.548 -> 1.406,
             // 8 rows 1.611 -> 1.465, 12 rows 1.887 -> 1.725; at 16 rows the split form wins again (1.890 vs 1.923)  [profiles/r03_small_ab.txt]
-            const bool one_launch = (long)bg * Hn <= 240 && !getenv("CAR_ATTN_SPLIT_SMALL");
+            const bool one_launch = (long)bg * Hn <= 240 && !CAR_KNOB("CAR_ATTN_SPLIT_SMALL");
             if (one_launch) gr.nsplit = 1;
-            { const char* ev = getenv("CAR_ATTN_NSPLIT"); if (ev) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) gr.nsplit = v; } }   // A/B knob: shorter attention workgroups
+            { const char* ev = CAR_KNOB("CAR_ATTN_NSPLIT"); if (ev) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) gr.nsplit = v; } }   // A/B knob: shorter attention workgroups
             // attention variant (decode2.hip; profiles/r02_kbench_*): 4 waves per (sequence, head) from 128 sequences up, 2 below; 16 in the one-launch small form
             gr.attn_variant = (one_launch && gr.nsplit == 1) ? 160 : ((gr.nsplit == 1 && bg < 128) ? 20 : 40); gr.attn_lds_pad = 0;
-            { const char* ev = getenv("CAR_ATTN_VARIANT"); if (ev) gr.attn_variant = atoi(ev); ev = getenv("CAR_ATTN_LDS_PAD"); if (ev) gr.attn_lds_pad = atoi(ev); }
+            { const char* ev = CAR_KNOB("CAR_ATTN_VARIANT"); if (ev) gr.attn_variant = atoi(ev); ev = CAR_KNOB("CAR_ATTN_LDS_PAD"); if (ev) gr.attn_lds_pad = atoi(ev); }
             // persistent attention grid: R resident workgroups per CU walk the (sequence, head) items in equal shares
             gr.attn_pgrid = 0;
-            { const char* ev = getenv("CAR_ATTN_PERSIST"); const int R = ev ? atoi(ev) : 0;
+            { const char* ev = CAR_KNOB("CAR_ATTN_PERSIST"); const int R = ev ? atoi(ev) : 0;
               if (R > 0 && R <= 16 && gr.nsplit == 1) { const long items = (long)bg * Hn, cap = (long)c->n_cu * R;
                   if (items > cap) { const long per = (items + cap - 1) / cap; gr.attn_pgrid = (int)((items + per - 1) / per); } } }
             sizes[gi][0] = M16 * D * 2; sizes[gi][1] = M16 * D * 2; sizes[gi][2] = M16 * Fh * 2; sizes[gi][3] = rup((size_t)bg * D * 2, 16);
@@ -512,11 +524,11 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     //                  offset per `gsteps` tokens instead of per token); the remainder runs on a single-step graph
     //   linear prio  : s_setprio on the linears / norms
     int phase = fast ? 0 : 1, gsteps = 1, lin_prio = 0;      // exact mode: the second chain enters half a layer late, so that attention meets linears, not attention
-    { const char* ev = getenv("CAR_PHASE_OFFSET"); if (ev) phase = atoi(ev) != 0; }
+    { const char* ev = CAR_KNOB("CAR_PHASE_OFFSET"); if (ev) phase = atoi(ev) != 0; }
     if (fast) {
         const char* ev;
-        ev = getenv("CAR_GRAPH_STEPS"); if (ev) { const int v = atoi(ev); if (v >= 1 && v <= 64) gsteps = v; }
-        ev = getenv("CAR_LINEAR_PRIO"); if (ev) lin_prio = atoi(ev) != 0;
+        ev = CAR_KNOB("CAR_GRAPH_STEPS"); if (ev) { const int v = atoi(ev); if (v >= 1 && v <= 64) gsteps = v; }
+        ev = CAR_KNOB("CAR_LINEAR_PRIO"); if (ev) lin_prio = atoi(ev) != 0;
     }
     if (NG < 2) phase = 0;
     bool capturing = false;
@@ -552,10 +564,11 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
                  (const void*)forced_tokens, (void*)logits_out);
         { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
-                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((getenv("CAR_NO_NORMX") ? 1 : 0) + (getenv("CAR_NO_SMALL_FUSE") ? 2 : 0)));
+                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0)));
           strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
+        { const char* k1 = CAR_KNOB("CAR_ATTN_F32_FORM"); const char* k2 = CAR_KNOB("CAR_LINEAR_PRIO"); char kb3[64]; snprintf(kb3, sizeof(kb3), "|x%s|%s", k1 ? k1 : "-", k2 ? k2 : "-"); strncat(keyb, kb3, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
-        const bool no_graph = getenv("CAR_NO_GRAPH") != nullptr;      // profiling aid: eager launches (PMC collection cannot follow graph replays)
+        const bool no_graph = CAR_KNOB("CAR_NO_GRAPH") != nullptr;      // profiling aid: eager launches (PMC collection cannot follow graph replays)
         // capture `k` steps into `ex` unless the cached exec already holds exactly this configuration
         auto get_exec = [&](hipGraphExec_t& ex, std::string& exkey, int k) -> bool {
             const std::string kk = key + "|k" + std::to_string(k);

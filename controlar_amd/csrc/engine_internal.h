@@ -122,6 +122,7 @@ struct car_ctx {
     int h_init[16] = {};
     SampleDyn h_dyn = {};
     int dbg_skip = 0;
+    int knob_hits = 0;      // development build: CAR_* switches found set while the last generate was enqueued (car_stats.dev_knobs_active)
     int n_cu = 256;       // compute units of the device (persistent-grid sizing)
     DevBuf rowimg;       // [b] int: image index of each row
     DevBuf rowunc; std::vector<int> h_rowunc;   // c2i: uncond-row marks (device + the host copy the async upload reads)
@@ -217,7 +218,7 @@ static inline char* off(void* p, size_t elems, size_t esz) { return (char*)p + e
 static inline const char* off(const void* p, size_t elems, size_t esz) { return (const char*)p + elems * esz; }
 
 static inline bool use_flash(const car_ctx* c, int head_dim) {
-    static const bool off_env = getenv("CAR_NO_FLASH") != nullptr;
+    static const bool off_env = CAR_KNOB("CAR_NO_FLASH") != nullptr;
     return c->mode == CAR_BF16 && head_dim == 64 && !off_env;
 }
 

@@ -817,14 +817,14 @@ static bool conv3_halo_plan(int mode, int amode, const GemmP& p, int* dev_out, v
     if (dev_out) *dev_out = dev;
     if (!(mode == 1 && amode == AMODE_CONV3 && p.Cin % 128 == 0 && (p.Ho & 15) == 0 && (p.Wo & 15) == 0 && (p.ups == 0 || p.ups == 1) && p.K == 9 * p.Cin && p.ldw % 8 == 0 &&
           (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.W % 16 == 0 && !p.swiglu && !p.out_f32 && p.act == ACT_NONE && (p.nb0 <= 1) && (p.nb1 <= 1) && p.alpha == 1.0f &&
-          p.N % 128 == 0 && !p.scale && p.bias_mode != BIAS_M && p.ldc % 8 == 0 && (!p.R || p.ldr % 8 == 0) && !getenv("CAR_GEMM_V1") && !getenv("CAR_NO_HALO"))) return false;
+          p.N % 128 == 0 && !p.scale && p.bias_mode != BIAS_M && p.ldc % 8 == 0 && (!p.R || p.ldr % 8 == 0) && !CAR_KNOB("CAR_GEMM_V1") && !CAR_KNOB("CAR_NO_HALO"))) return false;
     void* z = zero_page_for(dev);
     if (zero_out) *zero_out = z;
     return z != nullptr;
 }
 // the 64-channel-group kernel (the only one whose epilogue writes GroupNorm partials, GemmP::gn_part)
 extern "C" int car_conv3_halo64_ok(int mode, const GemmP* pp) {
-    return conv3_halo_plan(mode, AMODE_CONV3, *pp, nullptr, nullptr) && !getenv("CAR_CONV_HALO128") && !getenv("CAR_GN_UNFUSED");
+    return conv3_halo_plan(mode, AMODE_CONV3, *pp, nullptr, nullptr) && !CAR_KNOB("CAR_CONV_HALO128") && !CAR_KNOB("CAR_GN_UNFUSED");
 }
 // returns 0, or -1 when GemmP::gn_part is set on a call that cannot take conv3_halo64_kernel (the caller did not ask car_conv3_halo64_ok): nothing is launched
 extern "C" int car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_t st) {
@@ -832,7 +832,7 @@ extern "C" int car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_t
     if (p.nb0 <= 0) p.nb0 = 1;
     if (p.nb1 <= 0) p.nb1 = 1;
     if (mode == 1) {
-        if (amode != AMODE_CONV3 || (p.Ho & 15) || (p.Wo & 15) || getenv("CAR_CONV_LINEAR")) p.patch = 0;
+        if (amode != AMODE_CONV3 || (p.Ho & 15) || (p.Wo & 15) || CAR_KNOB("CAR_CONV_LINEAR")) p.patch = 0;
         dim3 g((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nb0 * p.nb1);
         // dynamic-LDS attributes are per device (a one-process multi-GPU host launches on several)
         static bool attr_set[16] = {}, attr3[16] = {}, attr4[16] = {};
@@ -841,8 +841,8 @@ extern "C" int car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_t
         if (conv3_halo_plan(mode, amode, p, &dev, &zero)) {
             p.zero = zero;
             const dim3 g3((p.N + BN - 1) / BN, (unsigned)((long)p.M / 256));
-            const bool halo128 = getenv("CAR_CONV_HALO128") != nullptr;
-            if (p.gn_part && (halo128 || getenv("CAR_GN_UNFUSED"))) return -1;
+            const bool halo128 = CAR_KNOB("CAR_CONV_HALO128") != nullptr;
+            if (p.gn_part && (halo128 || CAR_KNOB("CAR_GN_UNFUSED"))) return -1;
             if (!halo128) {          // default: the 75-KB form, two workgroups per CU (A/B switch: CAR_CONV_HALO128=1 -> the 131-KB kernel)
                 const size_t sh4 = (size_t)(CH64_HALO_PIX * 64 + 2 * BN * G2_BK) * 2;
                 if (!attr4[dev]) {
@@ -870,7 +870,7 @@ extern "C" int car_launch_gemm(int mode, int amode, const GemmP* pp, hipStream_t
         const bool al16 = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && p.ldw % 8 == 0 && p.sW0 % 8 == 0 && p.sW1 % 8 == 0 && p.sA0 % 8 == 0 && p.sA1 % 8 == 0;
         const long tiles = (long)((p.N + BN - 1) / BN) * ((p.M + G2_BM - 1) / G2_BM) * p.nb0 * p.nb1;
         (void)hipGetDevice(&dev);
-        const bool ok2 = dev >= 0 && dev < 16 && p.K % G2_BK == 0 && p.K >= 512 && al16 && tiles >= 512 && !getenv("CAR_GEMM_V1") &&
+        const bool ok2 = dev >= 0 && dev < 16 && p.K % G2_BK == 0 && p.K >= 512 && al16 && tiles >= 512 && !CAR_KNOB("CAR_GEMM_V1") &&
                          (amode == AMODE_PLAIN ? p.lda % 8 == 0 : (amode == AMODE_CONV3 && p.Cin % G2_BK == 0));
         if (ok2) {
             const size_t sh = (size_t)G2_NS * G2_STAGE * 2;

@@ -413,7 +413,7 @@ extern "C" void car_launch_groupnorm_ex(int mode, const void* x, const void* gam
     else hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), shb, st, x, part, HW, C);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, st, part, stats, nchunk, C, G, HW, eps);
     if (!y) return;              // statistics only
-    if (mode == 1 && C >= 8 && C <= 2048 && (C & (C - 1)) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && !getenv("CAR_GN_SCALAR")) {
+    if (mode == 1 && C >= 8 && C <= 2048 && (C & (C - 1)) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && !CAR_KNOB("CAR_GN_SCALAR")) {
         const int nslot = 256 / (C >> 3); int ppb = nslot * 8; if (ppb > HW) ppb = HW;
         hipLaunchKernelGGL(gn_apply_vec_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)gamma, (const bf16_t*)beta,
                            (bf16_t*)y, HW, C, G, swish, ppb);

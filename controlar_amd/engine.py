@@ -28,8 +28,9 @@ class Engine:
     """One context = one set of weights in one arithmetic mode ('fp32' exact | 'bf16' fast)."""
 
     def __init__(self, cfg: PathConfig, precision: str = "bf16", device: Optional[torch.device] = None, stream_priority: int = 0,
-                 weights_fp8: bool = False, kv_fp8: bool = False):
-        self.lib = L.load()
+                 weights_fp8: bool = False, kv_fp8: bool = False, dev: Optional[bool] = None):
+        # dev=True: the development build of the library (the CAR_* A/B switches exist only there; default: CONTROLAR_DEV_LIB=1 in the environment)
+        self.lib = L.load(dev)
         if not torch.cuda.is_available():
             raise RuntimeError("controlar_amd needs a HIP device (no CPU fallback)")
         dev = torch.device(device if device is not None else "cuda")

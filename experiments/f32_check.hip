@@ -275,9 +275,12 @@ static void attn_check_and_timing() {
                 std::vector<float> o0((size_t)b * dim), o1((size_t)b * dim);
                 CK(hipMemcpy(o0.data(), out, o0.size() * 4, hipMemcpyDeviceToHost));
                 CK(hipMemset(out, 0, o0.size() * 4));
-                car_launch_dec_attn_f32_ex(&p, b, 1, 0); CK(hipDeviceSynchronize()); CK(hipGetLastError());
-                CK(hipMemcpy(o1.data(), out, o1.size() * 4, hipMemcpyDeviceToHost));
-                if (memcmp(o0.data(), o1.data(), o0.size() * 4)) { ++fails; printf("attn b=%d pos=%d: fused form BITS DIFFER from split + combine\n", b, pos); }
+                for (int form : {1, 3, 4}) {
+                    CK(hipMemset(out, 0, o0.size() * 4));
+                    car_launch_dec_attn_f32_ex(&p, b, form, 0); CK(hipDeviceSynchronize()); CK(hipGetLastError());
+                    CK(hipMemcpy(o1.data(), out, o1.size() * 4, hipMemcpyDeviceToHost));
+                    if (memcmp(o0.data(), o1.data(), o0.size() * 4)) { ++fails; printf("attn b=%d pos=%d: one-launch form %d BITS DIFFER from split + combine\n", b, pos, form); }
+                }
             }
             // host check of sequence b-1, head 3
             const int bi = b - 1, h = 3;
@@ -293,8 +296,8 @@ static void attn_check_and_timing() {
             // valid rows actually read
             double rows = 0; for (int i = 0; i < b; ++i) { int len = 8 + (i * 7) % 33; rows += (pos + 1 - T) + len; }
             const double bytes = rows * H * 512.0;
-            double usv[2];
-            for (int fused = 0; fused < 2; ++fused) {
+            double usv[4];
+            for (int fused : {0, 1, 3}) {
                 for (int i = 0; i < 2; ++i) car_launch_dec_attn_f32_ex(&p, b, fused, 0);
                 CK(hipDeviceSynchronize());
                 CK(hipEventRecord(t0, 0));
@@ -305,7 +308,7 @@ static void attn_check_and_timing() {
                 usv[fused] = ms * 1000.0 / reps;
             }
             const double us = usv[0];
-            printf("attn b=%-3d pos=%-4d: max|err| %.3g %s   split+combine %8.1f us  %6.2f GB -> %5.2f TB/s | one launch %8.1f us -> %5.2f TB/s\n", b, pos, maxerr, maxerr < 2e-5 ? "ok" : "FAIL", us, bytes / 1e9, bytes / us / 1e6, usv[1], bytes / usv[1] / 1e6);
+            printf("attn b=%-3d pos=%-4d: max|err| %.3g %s   split+combine %8.1f us  %6.2f GB -> %5.2f TB/s | one launch %8.1f us -> %5.2f TB/s | 12-wave WGs %8.1f us -> %5.2f TB/s\n", b, pos, maxerr, maxerr < 2e-5 ? "ok" : "FAIL", us, bytes / 1e9, bytes / us / 1e6, usv[1], bytes / usv[1] / 1e6, usv[3], bytes / usv[3] / 1e6);
             fflush(stdout);
         }
         // batch invariance of the attention: sequence 0 alone vs inside the batch

@@ -63,8 +63,9 @@ def test_bench_config_presets(monkeypatch):
     a = args("--config", "2"); assert (a.cfg_scale, a.batch) == (4.0, 1)
     a = args("--config", "3"); assert (a.cfg_scale, a.batch, a.condition_type, a.adapter_size) == (4.0, 32, "depth", "base")
     a = args("--config", "4"); assert (a.cfg_scale, a.batch, a.image_h, a.image_w) == (4.0, 1, 768, 512)
-    a = args("--config", "5"); assert (a.batch, a.fp8_mfma, a.weights_fp8, a.adapter_size) == (8, False, True, "base")       # weight-only by default
-    a = args("--config", "5", "--fp8-mfma"); assert (a.batch, a.fp8_mfma, a.weights_fp8) == (8, True, True)                # W8A8 on request
+    a = args("--config", "5"); assert (a.batch, a.fp8_mfma, a.weights_fp8, a.adapter_size) == (8, True, True, "base")        # BASELINE configs[4] as named: W8A8 on the fp8 MFMA
+    a = args("--config", "5", "--fp8-weight-only"); assert (a.batch, a.fp8_mfma, a.weights_fp8) == (8, False, True)          # the weight-only variant (reported beside it)
+    assert args().exact_leg_steps == 2 and not args().no_variants                                                            # the default run times the bit-identical mode too
     a = args("--gpus", "8", "--steps", "20", "--warmup", "5"); assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
     a = args("--precision", "fp32"); assert (a.batch, a.vq_precision) == (384, "bf16")          # the tokens-exact configuration: fp32 KV of 384 sequences = 162 GB, bf16 pixels
     a = args("--precision", "fp32", "--vq-precision", "fp32", "--batch", "192"); assert (a.batch, a.vq_precision) == (192, "fp32")

@@ -22,9 +22,9 @@ def _mask(cs):
     return cs["mask"].cuda() if cs["mask"] is not None else None
 
 
-def _engine(cs, prec):
+def _engine(cs, prec, dev=None):
     from controlar_amd.engine import Engine
-    eng = Engine(cs["cfg"], prec)
+    eng = Engine(cs["cfg"], prec, dev=dev)
     eng.load_state_dict(cs["gsd"]); eng.load_state_dict(cs["vsd"]); eng.finalize()
     return eng
 
@@ -128,7 +128,7 @@ def test_exact_mode_is_batch_invariant(monkeypatch):
     softmax partial sums in another order).  At XL the same property is checked by `bench.py --precision fp32`: row 0 of a batch of 192 must
     reproduce all 1024 tokens of the B = 1 golden."""
     cs = load_case("tiny_depth_cfg4")
-    eng = _engine(cs, "fp32")
+    eng = _engine(cs, "fp32", dev=True)                 # the development build of the library: the CAR_* schedule switches exist only there
     B = cs["B"]
     reps = 9                                            # 2 x 9 x B rows: another tile count and, before the fix, another split count
     eng.encode_control(cs["img"].cuda())
@@ -408,7 +408,7 @@ def test_cfg_large_batch_chains_and_row_tiling(chains, monkeypatch):
     img = synth.canny_like_control(B, H, W)
     emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
     toks_o, logits_o = O.generate(gsd, cfg, emb, n_new, mask, cfg_scale=2.0, condition=img, return_logits=True)
-    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    eng = Engine(cfg, "bf16", dev=True); eng.load_state_dict(gsd); eng.finalize()      # CAR_CHAINS is a switch of the development build
     eng.encode_control(img.cuda())
     toks, logits = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=2.0, forced_tokens=toks_o, return_logits=True)
     d = (logits.cpu() - logits_o).abs()
@@ -533,7 +533,7 @@ def test_chain_schedule_knobs_do_not_change_tokens(chains, monkeypatch):
     B, H, W, n_new = 48, 128, 128, 24                       # 23 decode steps = 4 x 5 + 3
     img = synth.canny_like_control(B, H, W)
     emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
-    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    eng = Engine(cfg, "bf16", dev=True); eng.load_state_dict(gsd); eng.finalize()      # the switches exist only in the development build of the library
     eng.encode_control(img.cuda())
     monkeypatch.setenv("CAR_CHAINS", chains)
     monkeypatch.setenv("CAR_PHASE_OFFSET", "0"); monkeypatch.setenv("CAR_GRAPH_STEPS", "1"); monkeypatch.setenv("CAR_LINEAR_PRIO", "0")

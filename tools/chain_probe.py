@@ -1,5 +1,6 @@
 """GPU probe: two-chain overlap vs attention occupancy (CAR_ATTN_VARIANT / CAR_ATTN_LDS_PAD knobs).  Not a test."""
 import sys, os, time, json
+os.environ["CONTROLAR_DEV_LIB"] = "1"      # the CAR_* switches exist only in the development build of the library (csrc/build.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from controlar_amd import config as C, synth

@@ -1,6 +1,7 @@
 """GPU probe: decode-step time vs batch / chain count for the XL model (weights loaded once).  Not a test.
 usage: decode_probe.py xl 256,128 1024 1,2,4 [cfg_scale] [fp8|fp8mfma]"""
 import sys, os, time, json
+os.environ["CONTROLAR_DEV_LIB"] = "1"      # the CAR_* switches exist only in the development build of the library (csrc/build.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from controlar_amd import config as C, synth

@@ -1,6 +1,7 @@
 """GPU probe: where does the exact mode stop being batch-invariant?  Runs tests/test_parity_gpu.py::test_exact_mode_is_batch_invariant's inputs and reports the
 first (step, row, column) at which the logits of a sequence decoded alone and inside a 9x batch differ."""
 import os, sys
+os.environ["CONTROLAR_DEV_LIB"] = "1"      # the CAR_* switches exist only in the development build of the library (csrc/build.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch

@@ -1,6 +1,7 @@
 """GPU probe: A/B of decode-schedule knobs at a given batch inside ONE process (same box, same clocks).  Not a test.
 usage: mid_ab.py B cfg_scale n_new "K1=V1,K2=V2;K3=V3;..."   (knob sets separated by ';', the empty set = defaults)"""
 import sys, os, json
+os.environ["CONTROLAR_DEV_LIB"] = "1"      # the CAR_* switches exist only in the development build of the library (csrc/build.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from controlar_amd import config as C, synth

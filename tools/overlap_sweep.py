@@ -13,6 +13,7 @@ usage: overlap_sweep.py [B=768] [n_new=1024] [all|quick|persist|diag|hfuse]
 """
 import json
 import os
+os.environ["CONTROLAR_DEV_LIB"] = "1"      # the CAR_* switches exist only in the development build of the library (csrc/build.sh)
 import sys
 import time
 

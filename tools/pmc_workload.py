@@ -3,6 +3,7 @@ XL weights, B sequences, encode + prefill + a few eager decode steps.  CAR_DEBUG
 late (engine_generate.hip) so that the few profiled steps run over a long KV prefix.
 usage: pmc_workload.py B n_new [skip] [bf16|fp32]   -> decode steps profiled = n_new - 1 - skip at positions 120+skip .."""
 import os, sys
+os.environ["CONTROLAR_DEV_LIB"] = "1"      # the CAR_* switches exist only in the development build of the library (csrc/build.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("CAR_NO_GRAPH", "1")      # PMC collection cannot follow graph replays: eager launches, chains back to back
 import torch

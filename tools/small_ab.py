@@ -1,6 +1,7 @@
 """GPU probe: A/B of the small-batch decode schedule knobs inside ONE process (same box, same clocks).  Not a test.
 usage: small_ab.py 2,8,12,16,32 [n_new=1024] [cfg_scale=1.0]"""
 import sys, os, json
+os.environ["CONTROLAR_DEV_LIB"] = "1"      # the CAR_* switches exist only in the development build of the library (csrc/build.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from controlar_amd import config as C, synth
