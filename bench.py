@@ -310,23 +310,42 @@ def main():
     if twin > 0:
         img[twin], emb[twin], mask[twin] = img[0], emb[0], mask[0]
 
+    # the masks were built on the host: the first valid prompt position of this rank's batch is known without asking the device (car_sampling.first_valid_hint:
+    # car_generate then has no host wait at all)
+    first_valid = None
+    if not c2i:
+        nz = mask != 0
+        first_valid = int(torch.where(nz.any(dim=1), nz.to(torch.int64).argmax(dim=1), torch.full((mask.shape[0],), T, device=mask.device)).min())
     labels = None
     if c2i:
         labels = torch.stack([synth.class_labels(1, cfg.gpt.num_classes, seed=1234 + rank + world * j)[0] for j in range(args.batch)]).to(dev)
         if twin > 0:
             labels[twin] = labels[0]
 
+    stage_ev = []      # (encode start, generate start, vq start, end) events of every step, read after the timed region
+
     def one_step():
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        evs[0].record()
+        toks_, px_ = one_step_inner(evs)
+        evs[3].record()
+        stage_ev.append(evs)
+        return toks_, px_
+
+    def one_step_inner(evs):
         eng.encode_control(img)
+        evs[1].record()
         if c2i:
             toks = eng.generate(labels, n_new, None, cfg_scale=args.cfg_scale, sample_logits=args.sample_logits, top_k=(args.top_k if args.sample_logits else 0),
                                 top_p=args.top_p, temperature=args.temperature, seed=1234)
+            evs[2].record()
             return toks, vq_eng.vq_decode(toks, gh, gw)
         if args.sample_logits:
             toks = eng.generate(emb, n_new, mask, cfg_scale=args.cfg_scale, control_strength=1.0, sample_logits=True, top_k=args.top_k, top_p=args.top_p,
-                                temperature=args.temperature, seed=1234)
+                                temperature=args.temperature, seed=1234, first_valid=first_valid)
         else:
-            toks = eng.generate(emb, n_new, mask, cfg_scale=args.cfg_scale, control_strength=1.0)
+            toks = eng.generate(emb, n_new, mask, cfg_scale=args.cfg_scale, control_strength=1.0, first_valid=first_valid)
+        evs[2].record()
         if not args.overlap_vq:
             return toks, vq_eng.vq_decode(toks, gh, gw)
         side.wait_stream(torch.cuda.current_stream())
@@ -438,6 +457,12 @@ def main():
         }
         if parity:
             out["config"]["self_check"] = parity
+        try:      # where a step goes: events on the caller's stream around the three boundary calls (timed steps only), ms per step
+            tl = stage_ev[-args.steps:]
+            out["config"]["stage_ms"] = {"encode_control": sum(e[0].elapsed_time(e[1]) for e in tl) / len(tl), "generate": sum(e[1].elapsed_time(e[2]) for e in tl) / len(tl),
+                                         "vq_decode": sum(e[2].elapsed_time(e[3]) for e in tl) / len(tl)}
+        except Exception:
+            pass
         # VQ decoder cost in both arithmetics (the reference keeps vq_model in fp32, sample_t2i.py:43-47; both bench modes decode pixels in bf16 by default):
         # HIP-event time of car_vq_decode on a slice of this step's tokens, outside the timed region
         try:

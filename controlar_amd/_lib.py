@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcontrolar_hip.so")
 # Loaded when CONTROLAR_DEV_LIB=1 is in the environment or on request (`load(dev=True)`, `Engine(..., dev=True)`: tools/, the schedule-invariance tests).
 DEV_LIB_PATH = os.path.join(_HERE, "csrc", "libcontrolar_hip_dev.so")
 
-CAR_ABI_VERSION = 1
+CAR_ABI_VERSION = 2
 CAR_F32, CAR_BF16 = 0, 1
 CAR_DT_F32, CAR_DT_BF16, CAR_DT_I32, CAR_DT_I64, CAR_DT_U8 = 0, 1, 2, 3, 4
 CAR_RESIZE_NEAREST, CAR_RESIZE_BICUBIC_AC = 0, 1
@@ -47,7 +47,7 @@ class CarSampling(C.Structure):
     _fields_ = [
         ("cfg_scale", C.c_float), ("cfg_interval", C.c_int32), ("temperature", C.c_float), ("top_k", C.c_int32),
         ("top_p", C.c_float), ("sample_logits", C.c_int32), ("seed", C.c_uint64), ("control_strength", C.c_float),
-        ("reserved", C.c_int32 * 4),
+        ("first_valid_hint", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 

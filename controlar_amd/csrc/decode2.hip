@@ -689,7 +689,9 @@ extern "C" void car_launch_mask_first_valid(const unsigned char* mask, int* jmin
     hipLaunchKernelGGL(mask_first_valid_kernel, dim3(b), dim3(64), 0, st, mask, jmin, T);
 }
 // out[0] = min over v[0..n): the earliest attendable text position of the whole batch (the prefill window of engine_generate.hip starts there)
-__global__ __launch_bounds__(256) void min_int_kernel(const int* v, int n, int* out) {
+// `need` >= 0 and `flag`: the caller sized the prefill window from a HINT (car_sampling.first_valid_hint) instead of reading the minimum back; a minimum below the
+// window start means valid prompt rows were dropped: raise the sticky host-mapped flag (engine_internal.h check_sticky)
+__global__ __launch_bounds__(256) void min_int_kernel(const int* v, int n, int* out, int need, int* flag) {
     __shared__ int sm[4];
     int m = 0x7fffffff;
     for (int i = threadIdx.x; i < n; i += 256) m = min(m, v[i]);
@@ -697,9 +699,9 @@ __global__ __launch_bounds__(256) void min_int_kernel(const int* v, int n, int* 
     for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = min(min(sm[0], sm[1]), min(sm[2], sm[3]));
+    if (threadIdx.x == 0) { const int r = min(min(sm[0], sm[1]), min(sm[2], sm[3])); out[0] = r; if (flag && need >= 0 && r < need) *flag = 1; }
 }
-extern "C" void car_launch_min_int(const int* v, int n, int* out, hipStream_t st) { hipLaunchKernelGGL(min_int_kernel, dim3(1), dim3(256), 0, st, v, n, out); }
+extern "C" void car_launch_min_int(const int* v, int n, int* out, int need, int* flag, hipStream_t st) { hipLaunchKernelGGL(min_int_kernel, dim3(1), dim3(256), 0, st, v, n, out, need, flag); }
 
 // split-KV combine -> bf16 attention output (XP-packed or row-major)
 __global__ __launch_bounds__(64) void dec_attn2_combine_kernel(const float* part, bf16_t* out, int H, int nsplit, int dim, int out_packed) {

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(F32_WAVES * 64) void dec_gemm_f32_kernel(GemmFP p) 
     for (int i = 0; i < I; ++i)
 #pragma unroll
         for (int j = 0; j < J; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    // k-blocks in flight per wave.  Deeper (6 / 8 for the 2 x 2 tile, 136-209 VGPRs) was tried for chains that run in the shadow of another chain's attention, where
+    // a load takes about three times as long: SLOWER, the registers cost more residency than the depth buys (384 sequences, 3 chains: 17.55 -> 18.29 / 19.21 ms per step)
     constexpr int DEPTH = (I + J) >= 8 ? 3 : ((I + J) >= 4 ? 4 : 6);
     f4 wr[DEPTH][I], xv[DEPTH][J];
     const f4 z4 = (f4){0.f, 0.f, 0.f, 0.f};
@@ -411,7 +413,7 @@ static int launch_f32t(const GemmFP& p, int epi, hipStream_t st) {
 // tiled configurations: cfg = 1000 + 100·WN + 10·WM + KG.  The product picks among 1221 / 1212 / 1214 (car_pick_gemm_f32_cfg); the others are compiled
 // for the sweep of experiments/f32_check only (-DF32T_ALL_CONFIGS).
 static int launch_f32t_cfg(const GemmFP& p, int epi, int cfg, hipStream_t st) {
-    const int WN = (cfg - 1000) / 100;
+    const int WN = (cfg % 1000) / 100;
     if (p.K % 128 || p.N % (32 * WN) || (p.ldx & 3) || p.M < 1) return -1;
     const int len = p.K / 128;
     const bool sk2 = len % 2 == 0;
@@ -442,7 +444,7 @@ static int launch_f32_ij(const GemmFP& p, int epi, hipStream_t st) {
         if (sh > 48 * 1024 && sh > attr[E * 2 + X][dev]) {                                                                       \
             if (hipFuncSetAttribute((const void*)dec_gemm_f32_kernel<I, J, E, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return -1; \
             attr[E * 2 + X][dev] = sh; }                                                                                         \
-        hipLaunchKernelGGL((dec_gemm_f32_kernel<I, J, E, X>), g, b, sh, st, p);                                                  \
+        hipLaunchKernelGGL((dec_gemm_f32_kernel<I, J, E, X>), g, b, sh, st, p);                                            \
     } while (0)
     if (p.normx) { if (epi == FEPI_PLAIN) LG(FEPI_PLAIN, 1); else if (epi == FEPI_SWIGLU) LG(FEPI_SWIGLU, 1); else if (epi == FEPI_QKV) LG(FEPI_QKV, 1); else return -1; }
     else if (epi == FEPI_PLAIN) LG(FEPI_PLAIN, 0); else if (epi == FEPI_RESID) LG(FEPI_RESID, 0); else if (epi == FEPI_SWIGLU) LG(FEPI_SWIGLU, 0); else LG(FEPI_QKV, 0);

@@ -157,7 +157,7 @@ extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
         c->stats.dev_knobs_active = n;
     }
     *out = c->stats;
-    if (check_sticky(c)) return -1;        // sticky device-side error flags (this entry has just synchronised: everything enqueued so far has reported)
+    if (check_sticky(c)) return -1;        // sticky device-side error flags (this entry has waited for the end event of the last decode loop: everything enqueued up to it has reported)
     return 0;
 }
 

@@ -152,7 +152,7 @@ static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b_total, int 
     bool lin_prio = false; { const char* ev = CAR_KNOB("CAR_LINEAR_PRIO"); if (ev) lin_prio = atoi(ev) != 0; }
     auto gemm = [&](const std::string& wname, const void* X, long ldx, int N, int K, int epi, GemmFP q) {
         q.W = (const float*)Wp(c, wname + "#pk32"); q.X = (const float*)X; q.ldx = ldx; q.M = b; q.N = N; q.K = K;
-        const int cfg = car_pick_gemm_f32_cfg(b, N, K, epi);
+        int cfg = car_pick_gemm_f32_cfg(b, N, K, epi);
         const int J = cfg % 10, Mb = (b + 15) / 16;
         q.w_nt = (cfg < 1000 && (Mb + J - 1) / J == 1 ? 1 : 0) | (lin_prio ? 2 : 0);
         if (!q.W || car_launch_dec_gemm_f32_cfg(&q, epi, cfg, st)) bad = cfg ? cfg : -1;
@@ -331,17 +331,34 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
     // rounds 1-3 here) pushed all T = 120 rows of every sequence through the 36 layers.  The prefill now runs on the LAST Tv rows only, Tv = the longest valid
     // prompt of the batch rounded up to 8 (8-40 of 120 in the reference's caption statistics): every kernel of the prefill sees sequences of Tv rows, cache rows
     // and rope rows are offset by t0 = T - Tv, the mask by the same columns.  A valid row's arithmetic is unchanged (masked keys contributed exact zeros), so
-    // exact-mode tokens stay bit-identical.  Cost: ONE 4-byte device-to-host read of the batch minimum of `jmin` before the prefill is enqueued — the only host
-    // wait of car_generate, and only when a mask is given (CAR_NO_PREFILL_WINDOW=1 keeps all T rows and no wait).
+    // exact-mode tokens stay bit-identical.  Cost: the window size has to be known on the HOST before the prefill is enqueued — from the caller's
+    // car_sampling.first_valid_hint (no wait at all), else by ONE 4-byte device-to-host read of the batch minimum of `jmin`, the only host wait of car_generate
+    // and only when a mask is given (development build: CAR_NO_PREFILL_WINDOW=1 keeps all T rows and no wait).
     int Tv = T, t0 = 0;
-    if (emb_mask && !c2i && T > 8 && !CAR_KNOB("CAR_NO_PREFILL_WINDOW")) {
-        car_launch_min_int(jmin, b, jmin_min, st);
+    if (emb_mask && !c2i && T > 8 && T % 8 == 0 && (mode == CAR_BF16 || T <= 128) && !CAR_KNOB("CAR_NO_PREFILL_WINDOW")) {
         int hmin = 0;
-        HIPCHK(c, hipMemcpyAsync(&hmin, jmin_min, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        const int lmax = T - (hmin < 0 ? 0 : (hmin > T ? T : hmin));
-        Tv = (int)rup((size_t)(lmax < 1 ? 1 : lmax), 8); if (Tv > T) Tv = T;
-        t0 = T - Tv;
+        const bool hinted = sp->first_valid_hint > 0;
+        if (hinted) {
+            // the caller knows a lower bound of the first valid prompt position (it built the mask on the host): nothing is read back, the call only enqueues
+            // (the device checks the bound below and raises a sticky flag if valid rows would fall outside the window)
+            hmin = sp->first_valid_hint - 1;
+        } else {
+            // no hint: ONE 4-byte read of the batch minimum of `jmin` — the only host wait of car_generate (it also waits for whatever the caller had queued before)
+            car_launch_min_int(jmin, b, jmin_min, -1, nullptr, st);
+            HIPCHK(c, hipMemcpyAsync(&hmin, jmin_min, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+        }
+        // The window starts on a multiple of 16: a key keeps its slot inside the 16-wide k-blocks of the P·V product (one MFMA chain over the k-blocks in order:
+        // leading all-zero blocks add exact zeros), and the row softmax sums a column in the lane of its ABSOLUTE position (softmax_wave_kernel) — so a valid row's
+        // K / V rows and logits are the same bits whatever the batch-mates' prompt lengths make of t0 (tests/test_parity_gpu.py::test_exact_mode_prefill_window_invariance).
+        const int hm = hmin < 0 ? 0 : (hmin > T ? T : hmin);
+        t0 = (hm / 16) * 16; if (t0 > T - 8) t0 = ((T - 8) / 16) * 16; if (t0 < 0) t0 = 0;
+        Tv = T - t0;
+        if (Tv % 8) { Tv = T; t0 = 0; }
+        if (hinted && t0 > 0) {
+            if (!c->host_flags) { HIPCHK(c, hipHostMalloc((void**)&c->host_flags, 64, hipHostMallocMapped)); memset(c->host_flags, 0, 64); }
+            car_launch_min_int(jmin, b, jmin_min, t0, c->host_flags + 1, st);
+        }
     }
     const unsigned char* pmask = (const unsigned char*)c->maskb.p;             // the prefill's mask: [b][Tv]
     if (t0 > 0) {
@@ -424,7 +441,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             q.alpha = 0.125f; q.out_f32 = 1; q.nb0 = b; q.nb1 = Hn;
             q.sA0 = (long)Tv * 3 * D; q.sA1 = 64; q.sW0 = (long)Tv * 3 * D; q.sW1 = 64; q.sC0 = (long)Hn * Tv * Tv; q.sC1 = (long)Tv * Tv;
             car_launch_gemm(mode, AMODE_PLAIN, &q, st);
-            car_launch_softmax(mode, S, Tv, P, Tpw, (long)b * Hn * Tv, Tv, 1, pmask, Tv, Hn, st);
+            car_launch_softmax_at(mode, S, Tv, P, Tpw, (long)b * Hn * Tv, Tv, 1, pmask, Tv, Hn, t0, st);
         }
         if (!fused) {
             GemmP q = gp(P, Tpw, vT, Tpw, att, D, Tv, 64, Tpw);

@@ -26,7 +26,7 @@ int car_pick_gemm_cfg(int M, int N, int K, int epi);
 void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, int lds_pad, hipStream_t st);
 void car_launch_mask_first_valid(const unsigned char* mask, int* jmin, int b, int T, hipStream_t st);
 void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const float* rope, int b, int Tn, int H, int dim, int SA, int kv8, int t0, hipStream_t st);
-void car_launch_min_int(const int* v, int n, int* out, hipStream_t st);
+void car_launch_min_int(const int* v, int n, int* out, int need, int* flag, hipStream_t st);
 void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st);
 void car_launch_build_mask(const int64_t* emb_mask, const int* row_img, unsigned char* out, int b, int T, hipStream_t st);
 // canny.hip
@@ -51,6 +51,8 @@ void car_launch_layernorm(int mode, const void* x, const void* w, const void* b,
 void car_launch_rmsnorm(int mode, const NormP* p, long rows, hipStream_t st);
 void car_launch_softmax(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, int mask_mode,
                         const unsigned char* emb_mask, int Tq, int n_head, hipStream_t st);
+void car_launch_softmax_at(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, int mask_mode,
+                           const unsigned char* emb_mask, int Tq, int n_head, int col0, hipStream_t st);
 void car_launch_patchify(int mode, const void* img, int img_dtype, void* out, int B, int H, int W, int gh, int gw, int p, int Kpad,
                          int bicubic, const int* iy, const int* ix, const float* wy, const float* wx, hipStream_t st);
 void car_launch_vit_assemble(int mode, const void* tok, const void* cls, const void* pos, void* h, int B, int n, int D, hipStream_t st);
@@ -126,7 +128,7 @@ struct car_ctx {
     int n_cu = 256;       // compute units of the device (persistent-grid sizing)
     DevBuf rowimg;       // [b] int: image index of each row
     DevBuf rowunc; std::vector<int> h_rowunc;   // c2i: uncond-row marks (device + the host copy the async upload reads)
-    int* host_flags = nullptr;   // sticky error flags raised by device code, in host-mapped pinned memory ([0] = class label out of range): the kernel writes it
+    int* host_flags = nullptr;   // sticky error flags raised by device code, in host-mapped pinned memory ([0] = class label out of range, [1] = first_valid_hint too large): the kernel writes it
                                  // with a system-scope store, and every entry that takes this context reads it without a host wait (check_sticky)
     DevBuf canny_map;    // car_canny: uint8 [B,H,W] candidate/edge map + the "changed" flag
     car_t5_config t5 = {}; bool has_t5 = false;
@@ -149,6 +151,7 @@ struct car_ctx {
 static inline int check_sticky(car_ctx* c) {
     if (!c->host_flags) return 0;
     volatile int* f = c->host_flags;
+    if (f[1]) { f[1] = 0; FAIL(c, "car_generate: an earlier call passed a first_valid_hint beyond the first valid prompt position of its batch: valid prompt rows were left out of the prefill, its tokens are invalid"); }
     if (f[0]) { f[0] = 0; FAIL(c, "car_generate_c2i: an earlier call on this context received a class label outside [0, %d] (clamped to the null class on the device): its tokens are invalid", c->cfg.num_classes); }
     return 0;
 }

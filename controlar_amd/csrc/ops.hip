@@ -208,9 +208,81 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* S, long lds, 
         ET<T>::st(P + j, v);
     }
 }
+// Single pass, the row in registers (rows of up to 8 x 256 columns: the ViT encoder's 1025, the VQ AttnBlock's 1024): S is read once instead of three times.
+// Thread t owns columns t, t + 256, ... and sums them in that order, then block_sum — the statements of softmax_kernel, hence its bits.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_reg_kernel(const float* S, long lds, void* P_, long ldp, int ncols, int mask_mode,
+                                                          const unsigned char* emb_mask, int Tq, int n_head) {
+    __shared__ float sm[20];
+    const long r = blockIdx.x;
+    const float* s = S + r * lds; T* P = (T*)P_ + r * ldp;
+    const int i = mask_mode ? (int)(r % Tq) : 0;
+    const unsigned char* mk = mask_mode ? emb_mask + (r / Tq / n_head) * Tq : nullptr;
+    float v[8]; bool ok[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = threadIdx.x + k * 256;
+        ok[k] = j < ncols && (!mask_mode || (j <= i && (mk[j] || j == i)));
+        v[k] = ok[k] ? s[j] : 0.f;
+        if (ok[k]) mx = fmaxf(mx, v[k]);
+    }
+    mx = block_max(mx, sm);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = ok[k] ? expf(v[k] - mx) : 0.f; if (ok[k]) sum += v[k]; }
+    sum = block_sum(sum, sm);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int j = threadIdx.x + k * 256; if (j < ldp) ET<T>::st(P + j, ok[k] ? v[k] * inv : 0.f); }
+}
+
+// Rows of at most 128 columns (the prefill's Tv x Tv scores): one WAVE per row, and a column is summed in the lane of its ABSOLUTE position col0 + j — lane
+// (col0 + j) % 64, the two halves of a lane in position order, then a fixed butterfly.  A masked column adds an exact zero, so a valid row's probabilities are the
+// same bits whatever window [col0, col0 + ncols) of the prefix the prefill runs on (engine_generate.hip "prefill window": the batch-mates decide col0).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_wave_kernel(const float* S, long lds, void* P_, long ldp, long rows, int ncols, int mask_mode,
+                                                           const unsigned char* emb_mask, int Tq, int n_head, int col0) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* s = S + r * lds; T* P = (T*)P_ + r * ldp;
+    const int i = mask_mode ? (int)(r % Tq) : 0;
+    const unsigned char* mk = mask_mode ? emb_mask + (r / Tq / n_head) * Tq : nullptr;
+    float v[2]; bool ok[2]; int jj[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = lane + 64 * k - col0; jj[k] = j;
+        ok[k] = j >= 0 && j < ncols && (!mask_mode || (j <= i && (mk[j] || j == i)));
+        v[k] = ok[k] ? s[j] : 0.f;
+        if (ok[k]) mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v[k] = ok[k] ? expf(v[k] - mx) : 0.f;
+    const float sum = wave_sum(v[0] + v[1]);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) if (jj[k] >= 0 && jj[k] < ncols) ET<T>::st(P + jj[k], v[k] * inv);
+    for (int j = ncols + lane; j < ldp; j += 64) ET<T>::st(P + j, 0.f);      // zero padding of the row
+}
+
+// `col0`: absolute position of column 0 (the prefill window's start; 0 elsewhere)
+extern "C" void car_launch_softmax_at(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, int mask_mode,
+                                      const unsigned char* emb_mask, int Tq, int n_head, int col0, hipStream_t st) {
+    if (col0 >= 0 && col0 + ncols <= 128) {
+        const dim3 g((unsigned)((rows + 3) / 4));
+        if (mode == 1) hipLaunchKernelGGL(softmax_wave_kernel<bf16_t>, g, dim3(256), 0, st, S, lds, P, ldp, rows, ncols, mask_mode, emb_mask, Tq, n_head, col0);
+        else hipLaunchKernelGGL(softmax_wave_kernel<float>, g, dim3(256), 0, st, S, lds, P, ldp, rows, ncols, mask_mode, emb_mask, Tq, n_head, col0);
+        return;
+    }
+    if (ncols <= 2048 && ldp <= 2048) { LAUNCH_T(mode, softmax_reg_kernel, dim3(rows), dim3(256), st, S, lds, P, ldp, ncols, mask_mode, emb_mask, Tq, n_head); return; }
+    LAUNCH_T(mode, softmax_kernel, dim3(rows), dim3(256), st, S, lds, P, ldp, ncols, mask_mode, emb_mask, Tq, n_head);
+}
 extern "C" void car_launch_softmax(int mode, const float* S, long lds, void* P, long ldp, long rows, int ncols, int mask_mode,
                                    const unsigned char* emb_mask, int Tq, int n_head, hipStream_t st) {
-    LAUNCH_T(mode, softmax_kernel, dim3(rows), dim3(256), st, S, lds, P, ldp, ncols, mask_mode, emb_mask, Tq, n_head);
+    car_launch_softmax_at(mode, S, lds, P, ldp, rows, ncols, mask_mode, emb_mask, Tq, n_head, ncols <= 128 ? 0 : -1, st);
 }
 
 // ------------------------------------------------------------------ resize + patch unfold (dinov2_adapter.py:16-24 + HF patch conv as matmul)

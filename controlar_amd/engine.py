@@ -128,7 +128,9 @@ class Engine:
     def generate(self, cond: torch.Tensor, max_new_tokens: int, emb_masks: Optional[torch.Tensor] = None,
                  cfg_scale: float = 1.0, cfg_interval: int = -1, use_control: bool = True, control_strength: float = 1.0,
                  temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, sample_logits: bool = False, seed: int = 0,
-                 forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
+                 forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False, first_valid: Optional[int] = None):
+        """`first_valid`: a lower bound of the first valid (unpadded) prompt position over the batch, if the caller knows it — car_generate then sizes its prefill
+        window without reading the device mask back (no host wait).  A mask that is still on the host supplies it for free."""
         c2i = self.cfg.gpt.model_type == "c2i"
         if c2i and cond.device.type == "cpu" and cond.numel():
             # labels that are still on the host are checked for free; device-resident labels are checked on the device (sticky flag, stats())
@@ -148,8 +150,12 @@ class Engine:
         mask_t = None
         if emb_masks is not None:
             assert emb_masks.shape[0] == B and emb_masks.shape[-1] == T          # generate.py:185-186
+            if first_valid is None and emb_masks.device.type == "cpu" and emb_masks.numel():
+                nz = emb_masks.reshape(B, T) != 0
+                first_valid = int(torch.where(nz.any(dim=1), nz.to(torch.int64).argmax(dim=1), torch.full((B,), T)).min())
             mask_t = emb_masks.to(device=self.device, dtype=torch.int64).contiguous()
         sp = L.CarSampling()
+        sp.first_valid_hint = 0 if (first_valid is None or emb_masks is None) else max(0, min(int(first_valid), T)) + 1
         sp.cfg_scale, sp.cfg_interval, sp.temperature, sp.top_k = float(cfg_scale), int(cfg_interval), float(temperature), int(top_k or 0)
         sp.top_p, sp.sample_logits, sp.seed, sp.control_strength = float(top_p), int(bool(sample_logits)), int(seed), float(control_strength)
         out = torch.empty(B, max_new_tokens, dtype=torch.int32, device=self.device)

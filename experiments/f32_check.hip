@@ -144,7 +144,7 @@ static void tiled_correctness() {
                 if (!(maxerr < 1e-4)) { ++fails; printf("tiled check K=%d: cfg 22 vs fp64 %.3g FAIL\n", K, maxerr); }
             }
             for (int cfg : {1221, 1241, 1421, 1222, 1124, 1214, 1122, 1212}) {
-                if (!run(cfg, epi, out)) { if (!((cfg % 1000 == 241 || cfg % 1000 == 421) && (K / 128) % 2)) { printf("tiled cfg %d epi %d K=%d rejected\n", cfg, epi, K); ++fails; } continue; }
+                if (!run(cfg, epi, out)) { if (!((cfg % 1000 == 241 || cfg % 1000 == 421 || cfg == 2221) && (K / 128) % 2)) { printf("tiled cfg %d epi %d K=%d rejected\n", cfg, epi, K); ++fails; } continue; }
                 const bool same = out.size() == ref.size() && memcmp(out.data(), ref.data(), out.size() * 4) == 0;
                 if (!same) { ++fails; size_t bad = 0, first = 0; for (size_t i = 0; i < out.size(); ++i) if (memcmp(&out[i], &ref[i], 4)) { if (!bad) first = i; ++bad; }
                     printf("tiled cfg %d epi %d K=%d M=%d: BITS DIFFER (%zu of %zu, first at %zu: %.9g vs %.9g)\n", cfg, epi, K, M, bad, out.size(), first, out[first], ref[first]); }
@@ -179,7 +179,7 @@ static void tiled_correctness() {
                     printf("NX gemm (on-the-fly RMSNorm) K=%d M=%d vs fp64: max|err| %.3g %s\n", K, M, maxerr, maxerr < 2e-4 ? "ok" : "FAIL");
                 }
                 for (int cfg : {21, 42, 1221, 1241, 1421, 1222, 1124, 1214, 1122, 1212}) {
-                    if (!runx(cfg, epi, out)) { if (!((cfg == 1241 || cfg == 1421) && (K / 128) % 2)) { printf("NX cfg %d epi %d K=%d rejected\n", cfg, epi, K); ++fails; } continue; }
+                    if (!runx(cfg, epi, out)) { if (!((cfg == 1241 || cfg == 1421 || cfg == 2221) && (K / 128) % 2)) { printf("NX cfg %d epi %d K=%d rejected\n", cfg, epi, K); ++fails; } continue; }
                     const bool same = out.size() == ref.size() && memcmp(out.data(), ref.data(), out.size() * 4) == 0;
                     if (!same) { ++fails; printf("NX cfg %d epi %d K=%d M=%d: BITS DIFFER\n", cfg, epi, K, M); }
                 }
@@ -196,7 +196,7 @@ static void gemm_timing() {
     const Shape shapes[] = {{"wqkv", 3840, 1280, FEPI_PLAIN}, {"wo", 1280, 1280, FEPI_RESID}, {"w1|w3", 7168, 1280, FEPI_SWIGLU}, {"w2", 1280, 3584, FEPI_RESID}, {"logits", 16384, 1280, FEPI_PLAIN}};
     const int NL = 6;
     hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
-    for (int M : {64, 192, 384, 768}) for (const Shape& s : shapes) {
+    for (int M : {64, 128, 192, 384, 768}) for (const Shape& s : shapes) {
         if (argc_only_attn) break;
         const size_t wsz = (size_t)s.N * s.K;
         float *W, *X, *O; CK(hipMalloc(&W, wsz * NL * 4)); CK(hipMalloc(&X, (size_t)M * s.K * 4)); CK(hipMalloc(&O, (size_t)M * s.N * 4));
@@ -209,6 +209,7 @@ static void gemm_timing() {
         printf("M=%-3d %-6s N=%-5d K=%-4d %6.2f GFLOP pick %d:", M, s.name, s.N, s.K, gflop, pick);
         for (int cfg : {22, 21, 1221, 1241, 1421, 1222, 1124, 1214, 1122, 1212}) {
             if (cfg < 1000 && ((M <= 16 && cfg % 10 > 1) || (M > 16 && cfg % 10 < 2))) continue;
+            if ((cfg == 122 || cfg == 222) && M < 64) continue;
             if (cfg >= 1000 && M < 64) continue;
             const int nx = 0;
             auto launch = [&](int it) {

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAR_ABI_VERSION 1
+#define CAR_ABI_VERSION 2      /* 2: car_stats.dev_knobs_active, car_check_errors, car_sampling.first_valid_hint (round 4-5) */
 
 /* arithmetic mode of a context */
 enum { CAR_F32 = 0,   /* "exact" mode: fp32 weights/activations/FMA — parity contract vs the fp32 CPU reference */
@@ -85,7 +85,12 @@ typedef struct car_sampling {
     int32_t  sample_logits;    /* 0 = greedy topk(probs,1): ties -> lowest index   generate.py:71-73 */
     uint64_t seed;             /* counter-based RNG seed when sample_logits != 0 */
     float    control_strength; /* ignored (=1) when cfg_scale <= 1                 generate.py:87-92 */
-    int32_t  reserved[4];
+    int32_t  first_valid_hint; /* 0 = unknown.  Otherwise 1 + a LOWER bound of the first attendable position over all prompts of the call (left-padded captions,
+                                  sample_t2i.py:146-160): T - longest valid length, known to a caller that built the mask on the host.  With it car_generate sizes the
+                                  prefill window without reading the device mask back — no host wait, the call only enqueues (legal under stream capture).  Too
+                                  small a value only costs time; a value beyond the true minimum would drop valid prompt rows: it is checked on the device and
+                                  raises the sticky error flag (car_check_errors). */
+    int32_t  reserved[3];
 } car_sampling;
 
 typedef struct car_ctx car_ctx;

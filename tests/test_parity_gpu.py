@@ -124,8 +124,8 @@ def test_generate_is_deterministic_and_repeatable():
 
 def test_exact_mode_is_batch_invariant(monkeypatch):
     """Exact mode: a sequence decodes to the same BITS alone and as a row of a larger batch (logits included) — every exact-mode kernel sums one
-    fixed-order fp32 chain per output and the split-KV attention always folds 16 partials (a batch-dependent split count would fold a row's
-    softmax partial sums in another order).  At XL the same property is checked by `bench.py --precision fp32`: row 0 of a batch of 192 must
+    fixed-order fp32 arithmetic per output and the split-KV attention cuts the cache at ABSOLUTE positions (512 rows per split) and folds the pos/512 + 1
+    non-empty splits in position order (a batch-dependent split count would fold a row's softmax partial sums in another order).  At XL the same property is checked by `bench.py --precision fp32`: row 0 of a batch of 192 must
     reproduce all 1024 tokens of the B = 1 golden."""
     cs = load_case("tiny_depth_cfg4")
     eng = _engine(cs, "fp32", dev=True)                 # the development build of the library: the CAR_* schedule switches exist only there
@@ -150,6 +150,66 @@ def test_exact_mode_is_batch_invariant(monkeypatch):
     monkeypatch.setenv("CAR_PHASE_OFFSET", "0")
     t4 = eng.generate(emb.cuda(), cs["n_new"], mask.cuda(), cfg_scale=cs["cfg_scale"], control_strength=cs["control_strength"])
     assert torch.equal(t4.cpu(), t2)
+    eng.close()
+
+
+def test_exact_mode_prefill_window_invariance(monkeypatch):
+    """The prefill runs on a window of the left-padded prefix chosen by the LONGEST prompt of the batch (engine_generate.hip).  In the exact mode a sequence must not
+    notice: its tokens and logits are the same bits decoded alone (window of 24 of 120 rows), beside a 60-token prompt (72 rows), beside a full-length prompt (no
+    window), and with the window switched off — the window starts on a multiple of 16 (k-blocks of the P.V product) and the row softmax sums every column in the
+    lane of its absolute position (softmax_wave_kernel)."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    cfg = C.tiny_t2i(64, "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    T, cap, n_new = cfg.gpt.cls_token_num, cfg.gpt.caption_dim, 20
+    img = synth.canny_like_control(3, 128, 128)
+    emb, mask = synth.text_embeddings_with_lengths([9, 60, T], T, cap)
+    eng = Engine(cfg, "fp32", dev=True); eng.load_state_dict(gsd); eng.finalize()
+
+    def run(rows):
+        eng.encode_control(img[rows].cuda())
+        t, l = eng.generate(emb[rows].cuda(), n_new, mask[rows].cuda(), cfg_scale=1.0, return_logits=True)
+        return t.cpu()[0], l.cpu()[0]
+    t_alone, l_alone = run([0])
+    for rows in ([0, 1], [0, 2], [0, 1, 2]):
+        t, l = run(rows)
+        assert torch.equal(t, t_alone) and torch.equal(l, l_alone), rows
+    monkeypatch.setenv("CAR_NO_PREFILL_WINDOW", "1")
+    t, l = run([0])
+    assert torch.equal(t, t_alone) and torch.equal(l, l_alone)
+    # CFG doubles the rows (cond | uncond share the mask): same property
+    monkeypatch.delenv("CAR_NO_PREFILL_WINDOW")
+    eng.encode_control(img[[0]].cuda()); t1, l1 = eng.generate(emb[[0]].cuda(), n_new, mask[[0]].cuda(), cfg_scale=3.0, return_logits=True)
+    eng.encode_control(img[[0, 1]].cuda()); t2, l2 = eng.generate(emb[[0, 1]].cuda(), n_new, mask[[0, 1]].cuda(), cfg_scale=3.0, return_logits=True)
+    assert torch.equal(t1.cpu()[0], t2.cpu()[0]) and torch.equal(l1.cpu()[0], l2.cpu()[0])
+    eng.close()
+
+
+def test_first_valid_hint_replaces_the_host_wait_and_is_checked_on_the_device():
+    """car_sampling.first_valid_hint: a caller that knows where the shortest padding ends (a host-side mask) lets car_generate size its prefill window without
+    reading the device mask back.  Same tokens as the read-back path; a hint beyond the true first valid position would drop prompt rows — the device notices
+    and the next call on the context fails (sticky flag), as an out-of-range c2i label does."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    cfg = C.tiny_t2i(64, "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    T, cap = cfg.gpt.cls_token_num, cfg.gpt.caption_dim
+    img = synth.canny_like_control(2, 128, 128)
+    emb, mask = synth.text_embeddings_with_lengths([12, 30], T, cap)
+    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    want = eng.generate(emb.cuda(), 16, mask.cuda(), cfg_scale=1.0).cpu()                       # device mask, no hint: read-back path
+    got = eng.generate(emb.cuda(), 16, mask, cfg_scale=1.0).cpu()                               # host mask: hint derived for free (T - 30 = 90 -> window from 80)
+    assert torch.equal(got, want)
+    got = eng.generate(emb.cuda(), 16, mask.cuda(), cfg_scale=1.0, first_valid=40).cpu()        # a loose lower bound only costs time
+    assert torch.equal(got, want)
+    eng.generate(emb.cuda(), 16, mask.cuda(), cfg_scale=1.0, first_valid=T - 12)                # beyond the first valid position of the 30-token prompt
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="first_valid_hint"):
+        eng.generate(emb.cuda(), 16, mask.cuda(), cfg_scale=1.0)
+    got = eng.generate(emb.cuda(), 16, mask.cuda(), cfg_scale=1.0).cpu()                        # the flag is cleared by the call that reported it
+    assert torch.equal(got, want)
     eng.close()
 
 
