@@ -102,7 +102,11 @@ extern "C" int car_encode_control(car_ctx* c, const void* img, int32_t img_dtype
     NEED(c, c->ctrl_in, (size_t)B * n * g.dim * e);
     c->ctrl_B = B; c->ctrl_ntok = n;
     const bool flash = use_flash(c, hd);
-    const int chmax = flash ? 64 : 16;  // images per chunk: the unfused form is bounded by its fp32 score matrix (CH*heads*Tn*Tn*4 B)
+    // images per chunk.  The unfused (exact) form holds fp32 scores and probabilities, CH*heads*Tn*(Tn + Tpad)*4 B — 4.9 GB at 96 images of 1025 tokens x 6 heads;
+    // 384 images, ms per encode: 16 per chunk 501, 32 471, 48 452, 96 436 (profiles/r05_exact_probe_v7.txt); capped so the two tensors stay below 6 GB
+    int chmax = flash ? 64 : 96;
+    if (!flash) while (chmax > 8 && (size_t)chmax * nh * Tn * (size_t)(Tn + Tpad) * 4 > ((size_t)6 << 30)) chmax /= 2;
+    { const char* ev = CAR_KNOB("CAR_ENC_CHUNK"); if (ev && atoi(ev) >= 1 && atoi(ev) <= 256) chmax = atoi(ev); }
     const int CH = B < chmax ? B : chmax;
     NEED(c, c->ws[0], (size_t)CH * n * Kp * e);            // patches, later ctx
     NEED(c, c->ws[1], (size_t)CH * Tn * D * e);            // h

@@ -548,13 +548,34 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         ev = CAR_KNOB("CAR_LINEAR_PRIO"); if (ev) lin_prio = atoi(ev) != 0;
     }
     if (NG < 2) phase = 0;
+    // ---- exact mode, three chains: the FIRST positions run as ONE chain.  Chains buy overlap of one chain's KV stream with the others' linears at the price of
+    // re-streaming the weights per chain and of smaller GEMMs; while the KV prefix is short there is little to overlap (profiles/r05_exact_probe_v5_positions.txt,
+    // 384 sequences, ms per step, 1 / 3 chains: position 120 8.47 / 9.25, 220 10.08 / 10.44, 370 13.19 / 12.62, 629 18.50 / 17.45, 1120 28.87 / 27.04).  The
+    // cross-over sits where a sequence's KV rows cost ~0.6 of its share of the linears: rows* = 0.087 · P / (8 · dim · n_layer) attended rows (177 for XL).  The
+    // host knows the position of every replay, so the loop is two captured graphs; the per-chain (pos, step) scalars are rewritten between them.  Chains are
+    // row ranges of the same buffers and every kernel is batch-invariant: the switch does not touch a token.
+    int n_early = 0;
+    Grp grpE[1]; memset(grpE, 0, sizeof(grpE));
+    if (!fast && NG == 3 && mult == 1 && !CAR_KNOB("CAR_CHAINS") && !CAR_KNOB("CAR_NO_EARLY_CHAIN")) {
+        const double P = (double)g.n_layer * (4.0 * D * D + 3.0 * (double)D * Fh) + (double)V * D;
+        const int rows_star = (int)(0.087 * P / (8.0 * D * g.n_layer));
+        const int attended0 = emb_mask ? 24 : T;                       // attended prefix rows at the first decode step (left-padded captions: ~24 of 120 valid on average)
+        n_early = rows_star - attended0 - c->dbg_skip;
+        if (n_early > nsteps) n_early = nsteps;
+        if (n_early < 8) n_early = 0;
+        Grp& ge = grpE[0];
+        ge.b0 = 0; ge.bg = b; ge.nsplit = nsplit; ge.pos = pos; ge.step = step;
+        ge.sp = spp; ge.sp.step_ptr = step;
+    }
+    int NGc = NG, phasec = phase; Grp* grpc = grp;      // the schedule being enqueued / captured (main: NG chains; early: one chain)
     bool capturing = false;
     int step_rc = 0;
     auto step_one = [&](int gi, hipStream_t sg, hipEvent_t pev, hipStream_t pdst) {
-        if (fast) return enqueue_decode_step_fast(c, sb, grp[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, sg, pev, pdst, lin_prio);
-        return enqueue_decode_step(c, sb, b, grp[gi].b0, grp[gi].bg, S_max, n_tok, nsplit, use_control != 0, cs, grp[gi].sp, grp[gi].pos, grp[gi].step, fmask, sg, pev, pdst);
+        if (fast) return enqueue_decode_step_fast(c, sb, grpc[gi], b, SA, n_tok, use_control != 0, cs, fmask, fjmin, sg, pev, pdst, lin_prio);
+        return enqueue_decode_step(c, sb, b, grpc[gi].b0, grpc[gi].bg, S_max, n_tok, nsplit, use_control != 0, cs, grpc[gi].sp, grpc[gi].pos, grpc[gi].step, fmask, sg, pev, pdst);
     };
     auto enqueue_steps = [&](int k) {      // k consecutive decode steps of every chain
+        const int NG = NGc, phase = phasec;
         if (NG >= 2 && capturing) {         // the chains are parallel branches of the captured graph
             if (!phase) {
                 (void)hipEventRecord(c->ev_fork, st);
@@ -587,8 +608,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         const std::string key(keyb);
         const bool no_graph = CAR_KNOB("CAR_NO_GRAPH") != nullptr;      // profiling aid: eager launches (PMC collection cannot follow graph replays)
         // capture `k` steps into `ex` unless the cached exec already holds exactly this configuration
-        auto get_exec = [&](hipGraphExec_t& ex, std::string& exkey, int k) -> bool {
-            const std::string kk = key + "|k" + std::to_string(k);
+        auto get_exec = [&](hipGraphExec_t& ex, std::string& exkey, int k, const char* tag = "") -> bool {
+            const std::string kk = key + "|k" + std::to_string(k) + tag;
             if (ex && exkey == kk) return true;
             if (ex) { (void)hipGraphExecDestroy(ex); ex = nullptr; exkey.clear(); }
             hipGraph_t graph = nullptr;
@@ -603,16 +624,25 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             if (ok) exkey = kk;
             return ok;
         };
-        const int nrep = nsteps / gsteps, nrem = nsteps % gsteps;
+        const int nmain = nsteps - n_early;
+        const int nrep = nmain / gsteps, nrem = nmain % gsteps;
         bool graph_ok = !no_graph;
+        auto early = [&](bool on) { if (on) { NGc = 1; phasec = 0; grpc = grpE; } else { NGc = NG; phasec = phase; grpc = grp; } };
+        // the scalars of ALL chains at the switch: (pos, step) after n_early steps
+        for (int i = 0; i < 8; ++i) { c->h_init2[2 * i] = c->h_init[0] + n_early; c->h_init2[2 * i + 1] = c->h_init[1] + n_early; }
+        if (graph_ok && n_early > 0) { early(true); graph_ok = get_exec(c->gexec1, c->gkey1, 1, "|early"); early(false); }      // (exact mode: gexec1 is free, gsteps == 1)
         if (graph_ok && nrep > 0) graph_ok = get_exec(c->gexec, c->gkey, gsteps);
         if (graph_ok && nrem > 0) graph_ok = get_exec(gsteps > 1 ? c->gexec1 : c->gexec, gsteps > 1 ? c->gkey1 : c->gkey, 1);
         if (graph_ok && !step_rc) {
+            for (int i = 0; i < n_early; ++i) HIPCHK(c, hipGraphLaunch(c->gexec1, st));
+            if (n_early > 0 && nmain > 0) HIPCHK(c, hipMemcpyAsync(pos, c->h_init2, 64, hipMemcpyHostToDevice, st));
             for (int i = 0; i < nrep; ++i) HIPCHK(c, hipGraphLaunch(c->gexec, st));
             for (int i = 0; i < nrem; ++i) HIPCHK(c, hipGraphLaunch(gsteps > 1 ? c->gexec1 : c->gexec, st));
             c->stats.graph_used = 1;
         } else if (!step_rc) {
-            for (int i = 0; i < nsteps; ++i) enqueue_steps(1);
+            early(true); for (int i = 0; i < n_early; ++i) enqueue_steps(1); early(false);
+            if (n_early > 0 && nmain > 0) HIPCHK(c, hipMemcpyAsync(pos, c->h_init2, 64, hipMemcpyHostToDevice, st));
+            for (int i = 0; i < nmain; ++i) enqueue_steps(1);
         }
     }
     if (step_rc) { fence_out(c, caller); return -1; }        // c->err was set by the step builder

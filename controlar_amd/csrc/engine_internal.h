@@ -87,6 +87,7 @@ struct DevBuf {
         p = nullptr; cap = 0;
         ++g_alloc_gen;
         size_t want = bytes + (bytes >> 3) + 256;
+        // (an uncached allocation for the KV cache — hipDeviceMallocUncached, the stream is read once per step — changed nothing: 17.60 vs 17.58 ms per exact step)
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
         cap = want; return true;
     }
@@ -122,6 +123,7 @@ struct car_ctx {
     DevBuf maskw;        // [b, Tv] uint8: the mask columns of the prefill window
     std::vector<int> h_rowimg;          // host staging that must outlive the async copies of a generate call
     int h_init[16] = {};
+    int h_init2[16] = {};     // the chains' (pos, step) scalars at the switch from the early one-chain schedule to the main one (exact mode)
     SampleDyn h_dyn = {};
     int dbg_skip = 0;
     int knob_hits = 0;      // development build: CAR_* switches found set while the last generate was enqueued (car_stats.dev_knobs_active)

@@ -56,6 +56,34 @@ def test_xl_two_chains_teacher_forced_at_bench_shape(B, twin):
         assert agree[gold["margin"][0] > 2.0 * float(cal["ref_bf16_max"])].all()
 
 
+@pytest.mark.parametrize("B,rows", [(288, (0, 100, 250)), (192, (0, 150))])
+def test_xl_exact_mode_bit_identical_in_every_chain_of_the_default_schedule(B, rows):
+    """The bit-identical mode at model size, in a BATCH, on the schedule the library chooses by itself (what `bench.py --precision fp32` times): 288 sequences =
+    three chains of 96 rows with the early one-chain graph for the first positions, the 12-wave one-launch attention, on-the-fly RMSNorm linears on the tiled and
+    register fp32-MFMA kernels; 192 = two chains.  The input of the reference-minted golden (fp32 CPU reference, sample_t2i.py --precision none) sits in one row of
+    every chain: each must reproduce ALL 1024 reference tokens, free-running."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    gold = dict(np.load(os.path.join(GOLDEN, "xl_canny_512_cfg1.npz")))
+    _, H, W, seed, _ = [int(x) for x in gold["meta"]]
+    cfg = C.xl_t2i(1024, "small", "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=seed)
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    for r in rows[1:]:
+        img[r], emb[r], mask[r] = img[0], emb[0], mask[0]
+    eng = Engine(cfg, "fp32"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    toks = eng.generate(emb.cuda(), 1024, mask, cfg_scale=1.0).cpu().numpy()          # host mask: the prefill window comes from the hint, no host wait
+    st = eng.stats()
+    eng.close()
+    assert st["graph_used"] and st["decode_steps"] == 1023 and st["dev_knobs_active"] == 0
+    assert st["decode_kernels_per_step"] == (3 if B >= 288 else 2) * 186, st             # 5 kernels per layer and chain (+ 3 gather / control-add launches, logits, advance, sampler)
+    for r in rows:
+        neq = np.nonzero(toks[r] != gold["tokens"][0])[0]
+        assert len(neq) == 0, (r, int(neq[0]), len(neq))
+
+
 def test_xl_base_depth_cfg4_b64_vs_oracle_steps():
     """BASELINE config 3 shapes: DINOv2-base (bicubic resize), cfg 4 -> one chain of 128 rows [cond | uncond]."""
     from controlar_amd import config as C, synth

@@ -23,12 +23,15 @@ for B in batches:
     img = synth.canny_like_control(B, 512, 512).float().cuda()
     emb, mask = synth.text_embeddings(B, 120, 2048)
     emb = emb.float().cuda(); mask = mask.cuda()
-    eng.encode_control(img)
+    eng.encode_control(img); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); eng.encode_control(img); e1.record(); torch.cuda.synchronize()
+    enc_ms = e0.elapsed_time(e1)
     for ch in chains:
         os.environ["CAR_CHAINS"] = ch
         for rep in range(2):
             eng.generate(emb, skip + steps + 1, mask, cfg_scale=1.0); torch.cuda.synchronize()
             st = eng.stats()
         ms = st["decode_ms"] / st["decode_steps"]
-        print(json.dumps(dict(B=B, chains=ch, pos0=120 + skip, steps=st["decode_steps"], ms_per_step=round(ms, 4), prefill_ms=round(st["prefill_ms"], 1),
+        print(json.dumps(dict(B=B, chains=ch, pos0=120 + skip, steps=st["decode_steps"], ms_per_step=round(ms, 4), prefill_ms=round(st["prefill_ms"], 1), encode_ms=round(enc_ms, 1),
                               kernels=st["decode_kernels_per_step"], graph=st.get("graph_used"))), flush=True)
