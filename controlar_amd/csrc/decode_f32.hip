@@ -422,6 +422,8 @@ static int launch_f32t_cfg(const GemmFP& p, int epi, int cfg, hipStream_t st) {
         case 1212: return launch_f32t<2, 1, 2, 1, 4>(p, epi, st);
         case 1214: return launch_f32t<2, 1, 4, 1, 3>(p, epi, st);
 #ifdef F32T_ALL_CONFIGS
+        case 1114: return launch_f32t<1, 1, 4, 1, 4>(p, epi, st);
+        case 1118: return launch_f32t<1, 1, 8, 1, 3>(p, epi, st);
         case 1241: return sk2 ? launch_f32t<2, 4, 1, 2, 3>(p, epi, st) : -1;
         case 1421: return sk2 ? launch_f32t<4, 2, 1, 2, 3>(p, epi, st) : -1;
         case 1222: return launch_f32t<2, 2, 2, 1, 4>(p, epi, st);
@@ -476,16 +478,28 @@ extern "C" int car_launch_dec_gemm_f32_cfg(const GemmFP* p, int epi, int cfg, hi
 // within 5 % of its best everywhere; one m-block: 32 x 16.  The tiled kernel wins where there are many tiles per CU: w1|w3 and the logits from 128
 // rows (43.3 vs 49.2 us and 82.7 vs 98.4 at 192 rows), wqkv and — with 4 K-groups on 64 x 32 tiles — wo / w2 from 320 rows (43.4 / 17.2 / 43.2 vs
 // 46.5 / 18.5 / 45.2 us at 384).  Every choice yields the same bits.
-extern "C" int car_pick_gemm_f32_cfg(int M, int N, int K, int epi) {
+// `chains`: how many chains the step runs (engine_generate.hip).  With several, a chain's linears run BESIDE another chain's attention, which holds 24 of a CU's 32
+// wave slots (12-wave workgroups): two 4-wave workgroups of the tiled kernel fit into the remaining 8 where one 8-wave workgroup of the register kernel does, and they
+// keep the matrix pipe fed from their LDS rings while HBM is saturated.  384 sequences, mean position, ms per step (profiles/r05_exact_probe_v8/v9.txt):
+//   3 chains of 128 rows: register wqkv / wo / w2 17.52 | tiled wqkv 17.17 | tiled wqkv + wo / w2 16.65 (1114: 16.74, 1118: 16.84)
+//   2 chains of 192 rows: tiled wqkv 17.68, tiled wqkv + wo / w2 18.42 (80-workgroup grids at 192 rows: too few) — wo / w2 stay on the register kernel
+// ALONE (one chain) the register kernel is the faster one below 320 rows (wo at 192 rows: 11.3 vs 18.6 us).
+extern "C" int car_pick_gemm_f32_cfg2(int M, int N, int K, int epi, int chains) {
     const int Mb = (M + 15) / 16;
     const int I = N % 32 == 0 ? 2 : 1;
     const int reg = I * 10 + (Mb >= 2 ? 2 : 1);
     if (K % 128 || N % 64) return reg;
-    if (epi == FEPI_RESID) return M >= 320 ? 1214 : reg;
+    if (epi == FEPI_RESID) {
+        { const char* ev = CAR_KNOB("CAR_F32_RESID_CFG"); if (ev && M >= 64) return atoi(ev); }
+        if (M >= 320) return 1214;
+        return chains >= 3 && M >= 96 ? 1212 : reg;
+    }
     if (N >= 16384) return M >= 64 ? 1212 : reg;
-    if (N >= 4096) return M >= 128 ? 1212 : reg;
-    return M >= 320 ? 1212 : reg;
+    if (N >= 4096) return M >= 128 || (chains >= 2 && M >= 96) ? 1212 : reg;
+    { const char* ev = CAR_KNOB("CAR_F32_QKV_TILED_FROM"); if (ev) return M >= atoi(ev) ? 1212 : reg; }
+    return M >= 320 || (chains >= 2 && M >= 96) ? 1212 : reg;
 }
+extern "C" int car_pick_gemm_f32_cfg(int M, int N, int K, int epi) { return car_pick_gemm_f32_cfg2(M, N, K, epi, 1); }
 
 // =============================================================================================== attention
 // One workgroup (4 waves) per (head, sequence, split).  Split s covers the cache positions [s*AF_SPLIT, (s+1)*AF_SPLIT) ∩ [0, pos]: the

@@ -152,7 +152,7 @@ static int enqueue_decode_step(car_ctx* c, const StepBufs& sb, int b_total, int 
     bool lin_prio = false; { const char* ev = CAR_KNOB("CAR_LINEAR_PRIO"); if (ev) lin_prio = atoi(ev) != 0; }
     auto gemm = [&](const std::string& wname, const void* X, long ldx, int N, int K, int epi, GemmFP q) {
         q.W = (const float*)Wp(c, wname + "#pk32"); q.X = (const float*)X; q.ldx = ldx; q.M = b; q.N = N; q.K = K;
-        int cfg = car_pick_gemm_f32_cfg(b, N, K, epi);
+        int cfg = car_pick_gemm_f32_cfg2(b, N, K, epi, b_total / (b > 0 ? b : 1));
         const int J = cfg % 10, Mb = (b + 15) / 16;
         q.w_nt = (cfg < 1000 && (Mb + J - 1) / J == 1 ? 1 : 0) | (lin_prio ? 2 : 0);
         if (!q.W || car_launch_dec_gemm_f32_cfg(&q, epi, cfg, st)) bad = cfg ? cfg : -1;

@@ -73,6 +73,7 @@ void car_launch_prefill_rope_kv(int mode, void* qkv, void* kc, void* vc, const f
 void car_launch_pack_frag_f32(const void* src, void* dst, long N, long K, const void* colscale, hipStream_t st);
 int car_launch_dec_gemm_f32_cfg(const GemmFP* p, int epi, int cfg, hipStream_t st);
 int car_pick_gemm_f32_cfg(int M, int N, int K, int epi);
+int car_pick_gemm_f32_cfg2(int M, int N, int K, int epi, int chains);
 void car_launch_dec_attn_f32(const AttnFP* p, int b, hipStream_t st);
 void car_launch_dec_attn_f32_ex(const AttnFP* p, int b, int fused, hipStream_t st);
 }

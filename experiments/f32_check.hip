@@ -143,7 +143,7 @@ static void tiled_correctness() {
                 for (int m = 0; m < M; m += 7) for (int n = 0; n < N; n += 5) { double s = 0; for (int k = 0; k < K; ++k) s += (double)X[(size_t)m * K + k] * W[(size_t)n * K + k]; maxerr = fmax(maxerr, fabs(ref[(size_t)m * N + n] - s)); }
                 if (!(maxerr < 1e-4)) { ++fails; printf("tiled check K=%d: cfg 22 vs fp64 %.3g FAIL\n", K, maxerr); }
             }
-            for (int cfg : {1221, 1241, 1421, 1222, 1124, 1214, 1122, 1212}) {
+            for (int cfg : {1221, 1241, 1421, 1222, 1124, 1214, 1122, 1212, 1114, 1118}) {
                 if (!run(cfg, epi, out)) { if (!((cfg % 1000 == 241 || cfg % 1000 == 421 || cfg == 2221) && (K / 128) % 2)) { printf("tiled cfg %d epi %d K=%d rejected\n", cfg, epi, K); ++fails; } continue; }
                 const bool same = out.size() == ref.size() && memcmp(out.data(), ref.data(), out.size() * 4) == 0;
                 if (!same) { ++fails; size_t bad = 0, first = 0; for (size_t i = 0; i < out.size(); ++i) if (memcmp(&out[i], &ref[i], 4)) { if (!bad) first = i; ++bad; }
@@ -178,7 +178,7 @@ static void tiled_correctness() {
                     if (!(maxerr < 2e-4)) ++fails;
                     printf("NX gemm (on-the-fly RMSNorm) K=%d M=%d vs fp64: max|err| %.3g %s\n", K, M, maxerr, maxerr < 2e-4 ? "ok" : "FAIL");
                 }
-                for (int cfg : {21, 42, 1221, 1241, 1421, 1222, 1124, 1214, 1122, 1212}) {
+                for (int cfg : {21, 42, 1221, 1241, 1421, 1222, 1124, 1214, 1122, 1212, 1114, 1118}) {
                     if (!runx(cfg, epi, out)) { if (!((cfg == 1241 || cfg == 1421 || cfg == 2221) && (K / 128) % 2)) { printf("NX cfg %d epi %d K=%d rejected\n", cfg, epi, K); ++fails; } continue; }
                     const bool same = out.size() == ref.size() && memcmp(out.data(), ref.data(), out.size() * 4) == 0;
                     if (!same) { ++fails; printf("NX cfg %d epi %d K=%d M=%d: BITS DIFFER\n", cfg, epi, K, M); }
@@ -207,7 +207,7 @@ static void gemm_timing() {
         const double gflop = 2.0 * M * s.N * s.K / 1e9;
         const int pick = car_pick_gemm_f32_cfg(M, s.N, s.K, s.epi);
         printf("M=%-3d %-6s N=%-5d K=%-4d %6.2f GFLOP pick %d:", M, s.name, s.N, s.K, gflop, pick);
-        for (int cfg : {22, 21, 1221, 1241, 1421, 1222, 1124, 1214, 1122, 1212}) {
+        for (int cfg : {22, 21, 1221, 1241, 1421, 1222, 1124, 1214, 1122, 1212, 1114, 1118}) {
             if (cfg < 1000 && ((M <= 16 && cfg % 10 > 1) || (M > 16 && cfg % 10 < 2))) continue;
             if ((cfg == 122 || cfg == 222) && M < 64) continue;
             if (cfg >= 1000 && M < 64) continue;

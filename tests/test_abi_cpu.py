@@ -190,8 +190,9 @@ def test_exact_mode_tile_choice_and_norm_partials_are_valid_for_every_model_size
     from controlar_amd import _lib
     from controlar_amd.config import ffn_hidden_dim
     lib = _lib.load()
-    pick32 = lib.car_pick_gemm_f32_cfg
-    pick32.restype = C.c_int; pick32.argtypes = [C.c_int] * 4
+    pick32 = lib.car_pick_gemm_f32_cfg2
+    pick32.restype = C.c_int; pick32.argtypes = [C.c_int] * 5
+    lib.car_pick_gemm_f32_cfg.restype = C.c_int; lib.car_pick_gemm_f32_cfg.argtypes = [C.c_int] * 4
     pick = lib.car_pick_gemm_cfg
     pick.restype = C.c_int; pick.argtypes = [C.c_int] * 4
     FEPI_PLAIN, FEPI_RESID, FEPI_SWIGLU, FEPI_QKV = 0, 1, 2, 3
@@ -199,7 +200,8 @@ def test_exact_mode_tile_choice_and_norm_partials_are_valid_for_every_model_size
         fh, V = ffn_hidden_dim(dim), 16384
         for M in list(range(1, 18)) + [32, 36, 64, 96, 192, 384, 768]:
             for N, K, epi in [(3 * dim, dim, FEPI_QKV), (dim, dim, FEPI_RESID), (2 * fh, dim, FEPI_SWIGLU), (dim, fh, FEPI_RESID), (V, dim, FEPI_PLAIN)]:
-                cfg = pick32(M, N, K, epi)
+              for chains in (1, 2, 3):          # the tile choice may depend on how many chains run side by side, never the arithmetic
+                cfg = pick32(M, N, K, epi, chains)
                 if cfg >= 1000:      # round 5: the LDS-tiled kernel, cfg = 1000 + 100 WN + 10 WM + KG; it needs 8 equal K slices and whole 32·WN-row tiles
                     WN, WM, KG = (cfg - 1000) // 100, (cfg // 10) % 10, cfg % 10
                     assert cfg in (1221, 1212, 1214), (dim, M, N, K, cfg)       # the configurations the product library instantiates
@@ -208,6 +210,8 @@ def test_exact_mode_tile_choice_and_norm_partials_are_valid_for_every_model_size
                 I, J = cfg // 10, cfg % 10
                 assert I in (1, 2, 4) and J in (1, 2, 4), (dim, M, N, K, cfg)
                 assert N % (16 * I) == 0 and K % 16 == 0 and (epi != FEPI_SWIGLU or I >= 2), (dim, M, N, K, cfg)
+                if chains == 1:
+                    assert cfg == lib.car_pick_gemm_f32_cfg(M, N, K, epi)
         for M in range(1, 49):
             for N, K in [(dim, dim), (dim, fh)]:                      # the two RESID producers of the residual stream
                 I = pick(M, N, K, 1) // 100
