@@ -254,16 +254,39 @@ def main():
     else:
         cfg = {"xl": C.xl_t2i, "b": C.b_t2i}[args.model](grid * grid, adapter_size=args.adapter_size, condition_type=args.condition_type)
     n_new = gh * gw
-    log("synthesising weights")
-    gsd, vsd = synth.path_state_dicts(cfg, seed=0)          # identical on every rank (seeded CPU generator)
     # Two contexts, as the reference keeps two modules (gpt_model, vq_model).
     eng = Engine(cfg, args.precision, device=dev, weights_fp8=("mfma" if args.fp8_mfma else args.weights_fp8), kv_fp8=args.kv_fp8)
     vq_eng = Engine(cfg, args.vq_precision, device=dev)
-    log("loading weights into the HIP contexts")
-    eng.load_state_dict(gsd, finalize=True)
-    vq_eng.load_state_dict(vsd, finalize=True)
+    sds = {}
+
+    def build_only():
+        log("synthesising weights")
+        sds["g"], sds["v"] = synth.path_state_dicts(cfg, seed=0)          # deterministic (seeded CPU generator)
+        log("loading weights into the HIP contexts")
+        eng.load_state_dict(sds["g"], finalize=True)
+        vq_eng.load_state_dict(sds["v"], finalize=True)
+    # N > 1: the weights are synthesised and packed ONCE per node (rank 0) and handed to the other ranks as packed images (car_export_packed / car_import_packed:
+    # plain copies) — eight ranks each spending 11 s of host synthesis on one shared host is start-up time, not work (dist.load_weights_once)
+    import hashlib
+    from controlar_amd.dist import load_weights_once
+    tag = hashlib.blake2b((repr(bytes(eng._cc)) + repr(bytes(vq_eng._cc)) + args.precision + args.vq_precision + eng.lib.car_build_id().decode()).encode(), digest_size=8).hexdigest()
+    cdir = os.environ.get("CONTROLAR_PACK_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"controlar_amd_bench_{os.getuid()}"))
+    pk = [os.path.join(cdir, f"synth0_{tag}_{k}.carpk") for k in ("gpt", "vq")]
+
+    def build_and_export():
+        build_only()
+        os.makedirs(cdir, exist_ok=True)
+        for e_, f_ in ((eng, pk[0]), (vq_eng, pk[1])):
+            e_._check(e_.lib.car_export_packed(e_._h, (f_ + f".tmp{os.getpid()}").encode()), "car_export_packed")
+            os.replace(f_ + f".tmp{os.getpid()}", f_)
+
+    def import_packed():
+        for e_, f_ in ((eng, pk[0]), (vq_eng, pk[1])):
+            e_._check(e_.lib.car_import_packed(e_._h, f_.encode()), "car_import_packed")
+    how = load_weights_once(dist, rank, pk, build_and_export, import_packed, build_only)
+    gsd, vsd = sds.get("g"), sds.get("v")                   # None on a rank that imported the packed images (only rank 0 at N = 1 needs them: the CPU baseline)
     side = torch.cuda.Stream(device=dev)
-    log("weights ready")
+    log(f"weights ready ({how})")
 
     # ---- inputs.  Global image g (seeds 1234 + g) belongs to rank g % world (strided shards, sample_t2i_ddp.py:131).  Rank 0 builds one shard
     # at a time in a packed host buffer and sends it to its rank (dist.scatter_inputs); --input-dist local: every rank builds its own.
@@ -447,7 +470,7 @@ def main():
                        "input_distribution_s": t_bcast, "input_wire_bytes": 0 if (args.input_dist == "local" or world == 1) else shard_bytes * (world - 1),
                        "input_scatter_probe_s": t_probe, "input_scatter_probe_bytes": probe_bytes,
                        "input_scatter_probe_gb_per_s": (probe_bytes / t_probe / 1e9) if t_probe > 0 else None,
-                       "token_gather_s": t_gather, "graph": st["graph_used"],
+                       "token_gather_s": t_gather, "graph": st["graph_used"], "weights": how + (" on rank 0, packed images imported by the other ranks" if world > 1 else ""),
                        "decode_kernels_per_step": st["decode_kernels_per_step"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": measured_traffic()[0], "traffic_note": measured_traffic()[1],
@@ -469,6 +492,8 @@ def main():
             nb = min(args.batch, 48)
             vq_ms = {}
             for prec_ in ("bf16", "fp32"):
+                if prec_ != args.vq_precision and vsd is None:      # this rank imported packed images: no state dict at hand for a second decoder context
+                    continue
                 ve = vq_eng if prec_ == args.vq_precision else Engine(cfg, prec_, device=dev)
                 if ve is not vq_eng:
                     ve.load_state_dict(vsd, finalize=True)

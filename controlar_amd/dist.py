@@ -221,3 +221,33 @@ def timed_steps(dist, device, step_fn, steps: int, warmup: int, sync_fn=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, out
+
+
+def load_weights_once(dist, rank: int, files, build_and_export, import_packed, build_only=None):
+    """N ranks of one node, one set of weights: rank 0 builds them ONCE (checkpoint load or synthesis, device-side packing, car_finalize_weights) and writes the packed
+    images (`build_and_export()` -> files under a directory every rank can read, written atomically); after a barrier every other rank restores them with plain
+    copies (`import_packed()`, car_import_packed: ~seconds) instead of repeating 10+ s of host work per rank on a host that eight ranks share.  A rank whose import
+    fails (foreign build id, truncated file) falls back to `build_only()`, the single-process path.  `dist` None or one rank: `build_only()`.
+    Returns "built" | "imported" | "fallback"."""
+    import os
+    build_only = build_only or build_and_export
+    if dist is None or dist.get_world_size() == 1:
+        build_only()
+        return "built"
+    if rank == 0:
+        if all(os.path.exists(f) for f in files):
+            try:
+                import_packed(); how = "imported"
+            except Exception:
+                build_and_export(); how = "built"
+        else:
+            build_and_export(); how = "built"
+        dist.barrier()
+        return how
+    dist.barrier()
+    try:
+        import_packed()
+        return "imported"
+    except Exception:
+        build_only()
+        return "fallback"

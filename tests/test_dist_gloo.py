@@ -209,3 +209,53 @@ def test_gpus_flag_respawns_under_torchrun():
     # --gpus 1, or an environment that already carries WORLD_SIZE (the driver's torchrun launch): no respawn
     out1 = subprocess.run([sys.executable, probe, "--gpus", "1", "--batch", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert out1.returncode == 0 and json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 1
+
+
+def _weights_once_worker(rank, world, port, tmpdir, q):
+    import torch.distributed as dist
+    import controlar_amd.dist as cdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    files = [os.path.join(tmpdir, "gpt.carpk"), os.path.join(tmpdir, "vq.carpk")]
+    calls = []
+
+    def build_and_export():
+        calls.append("build+export")
+        for f in files:
+            with open(f + ".tmp", "w") as fh:
+                fh.write("weights of build X")
+            os.replace(f + ".tmp", f)
+
+    def import_packed():
+        calls.append("import")
+        for f in files:
+            if open(f).read() != "weights of build X":
+                raise RuntimeError("foreign file")
+    how1 = cdist.load_weights_once(dist, rank, files, build_and_export, import_packed, build_only=lambda: calls.append("build"))
+    how2 = cdist.load_weights_once(dist, rank, files, build_and_export, import_packed, build_only=lambda: calls.append("build"))     # second start: the files exist
+    dist.barrier()
+    if rank == 0:
+        open(files[1], "w").write("garbage")                                                                                     # a stale / foreign image
+    dist.barrier()
+    how3 = cdist.load_weights_once(dist, rank, files, build_and_export, import_packed, build_only=lambda: calls.append("build"))
+    q.put((rank, how1, how2, how3, list(calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_weights_are_built_once_per_node_world2(tmp_path):
+    """bench.py at N > 1: rank 0 synthesises / packs the weights once and exports the packed images, the other ranks import them after a barrier (never before the
+    files are complete); existing files are re-used; a rank that cannot import falls back to building."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_weights_once_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (_, a1, a2, a3, c0), (_, b1, b2, b3, c1) = res
+    assert (a1, b1) == ("built", "imported") and (a2, b2) == ("imported", "imported")
+    assert a3 == "built" and b3 == "imported"            # rank 0 found a foreign file, rebuilt and re-exported before the barrier
+    assert c0 == ["build+export", "import", "import", "build+export"] and c1 == ["import", "import", "import"]
