@@ -452,7 +452,7 @@ extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStr
         switch (cfg) {
 #define CASE(I, J) case I * 100 + J * 10: if (f8 == 2) launch_gemm_ij<I, J, 4, 2, 2>(*p, epi, st); else if (f8) launch_gemm_ij<I, J, 4, 1, 2>(*p, epi, st); else launch_gemm_ij<I, J, 4, 0, 2>(*p, epi, st); break; \
                    case I * 100 + J * 10 + 1: if (f8 == 2) launch_gemm_ij<I, J, 8, 2, 2>(*p, epi, st); else if (f8) launch_gemm_ij<I, J, 8, 1, 2>(*p, epi, st); else launch_gemm_ij<I, J, 8, 0, 2>(*p, epi, st); break;
-            CASE(1, 1) CASE(1, 2) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
+            CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
 #undef CASE
             default: return -1;
         }

@@ -27,13 +27,18 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     const size_t kv_layer = (size_t)b_total * Hn * SA * 64, kv_off = (size_t)b0 * Hn * SA * 64;
     bf16_t* h = (bf16_t*)sb.h + (size_t)b0 * D;
     const bool f8 = g.decode_weight_fp8 != 0;
+    int normx_max = 48; bool normx_j4 = false;
+    { const char* ev = CAR_KNOB("CAR_NORMX_MAX"); if (ev) normx_max = atoi(ev); ev = CAR_KNOB("CAR_NORMX_J4"); if (ev) normx_j4 = atoi(ev) != 0; }
     int nk = 0, bad_cfg = 0;
     // returns the number of sum-of-squares partials per row the kernel leaves in p.ssq_out (0 if it writes none)
     auto gemm = [&](const std::string& wname, const bf16_t* X, int N, int K, int epi, GemmDP gp_) -> int {
         GemmDP p = gp_;
         p.W = (const bf16_t*)Wp(c, wname + (f8 ? "#pk8" : "#pk")); p.X = X; p.M = b; p.N = N; p.K = K;
         p.wscale = f8 ? (const float*)Wp(c, wname + "#sc") : nullptr; p.f8_mfma = g.decode_weight_fp8 == 2;
-        const int cfg = car_pick_gemm_cfg(b, N, K, epi);
+        int cfg = car_pick_gemm_cfg(b, N, K, epi);
+        // 49-64 rows behind an on-the-fly norm: ALL four m-blocks in one workgroup (J = 4), so the row statistics are folded once per weight tile instead of
+        // once per (weight tile, m-block) — 240 workgroups of wqkv instead of 960, each re-reading the same 20 KB of partials (profiles/r04_lat_probe_v5_rows64.txt)
+        if (p.ssq_in && b > 48 && b <= 64 && normx_j4) cfg = ((epi == EPI_SWIGLU || N >= 6144) ? 200 : 100) + 40 + 1;
         const int I = cfg / 100, J = (cfg / 10) % 10, Mb = (b + 15) / 16;
         p.w_nt = ((Mb + J - 1) / J == 1 ? 1 : 0) | (prio ? 2 : 0);      // bit 0: non-temporal weight stream, bit 1: raised wave priority
         if (p.ssq_out) p.ssq_ld = N / (16 * (I >= 2 ? 2 : 1));
@@ -57,7 +62,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     // ~6 us per layer) the measured layer goes 37.0 -> 34.4 us at 2 rows, 39.4 -> 35.7 at 8, 66.5 -> 61.6 at 32; at 64 rows it is a draw (83.3 / 82.9: the
     // 960 workgroups of wqkv each repeat the row statistics) and at 128 a loss (120 / 125), so larger chains keep the norm kernels.  The first norm of layer 0
     // (token gather) and of the three control-add layers changes the stream before it is normed: those keep the prologue / kernel form.
-    const bool normx = b <= 48 && D % 128 == 0 && D <= 2048 && fb.ssq != nullptr && !CAR_KNOB("CAR_NO_NORMX");      // D/32 and D/16 partials per row: multiples of 4, at most 128 (the fold's 16-byte loads)
+    const bool normx = b <= normx_max && D % 128 == 0 && D <= 2048 && fb.ssq != nullptr && !CAR_KNOB("CAR_NO_NORMX");      // D/32 and D/16 partials per row: multiples of 4, at most 128 (the fold's 16-byte loads)
     int ssq_np = 0;                                                   // partials per row currently valid in fb.ssq (0: none)
     bf16_t* hc = h;                                                  // the residual stream; ping-pongs with `halt` when a control token is added
     bf16_t* halt = (bf16_t*)sb.xn + (size_t)b0 * D;                  // (the prefill's xn buffer is idle during decode)
@@ -604,7 +609,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
                                   grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0)));
           strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
-        { const char* k1 = CAR_KNOB("CAR_ATTN_F32_FORM"); const char* k2 = CAR_KNOB("CAR_LINEAR_PRIO"); char kb3[64]; snprintf(kb3, sizeof(kb3), "|x%s|%s", k1 ? k1 : "-", k2 ? k2 : "-"); strncat(keyb, kb3, sizeof(keyb) - strlen(keyb) - 1); }
+        { const char* k1 = CAR_KNOB("CAR_ATTN_F32_FORM"); const char* k2 = CAR_KNOB("CAR_LINEAR_PRIO"); const char* k3 = CAR_KNOB("CAR_NORMX_MAX"); const char* k4 = CAR_KNOB("CAR_NORMX_J4"); char kb3[64]; snprintf(kb3, sizeof(kb3), "|x%s|%s|%s|%s", k1 ? k1 : "-", k2 ? k2 : "-", k3 ? k3 : "-", k4 ? k4 : "-"); strncat(keyb, kb3, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
         const bool no_graph = CAR_KNOB("CAR_NO_GRAPH") != nullptr;      // profiling aid: eager launches (PMC collection cannot follow graph replays)
         // capture `k` steps into `ex` unless the cached exec already holds exactly this configuration

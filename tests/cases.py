@@ -36,3 +36,16 @@ def load_case(name):
     return dict(cfg=cfg, gold=gold, B=B, H=H, W=W, img=img, emb=emb, mask=mask, gsd=gsd, vsd=vsd,
                 cfg_scale=float(gold["cfg_scale"]), control_strength=float(gold["control_strength"]),
                 cfg_interval=interval, n_new=(H // 16) * (W // 16))
+
+
+def record_measured(name, **vals):
+    """Append a measured deviation to gpurun_out/parity_measured.jsonl (merged back from the GPU box; the round's copy is committed under profiles/):
+    the tolerances of the bf16 pixel tests are 1.5 x what these lines say."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_measured.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **{k: (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in vals.items()}}) + "\n")
+    except OSError:
+        pass

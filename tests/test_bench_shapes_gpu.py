@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.cases import GOLDEN
+from tests.cases import GOLDEN, record_measured
 
 pytestmark = pytest.mark.gpu
 
@@ -116,7 +116,7 @@ def test_xl_base_depth_cfg4_b64_vs_oracle_steps():
     eng.close()
 
 
-@pytest.mark.parametrize("prec,B,atol,mtol", [("bf16", 33, 0.6, 0.04), ("fp32", 17, 2e-3, 1e-4)])
+@pytest.mark.parametrize("prec,B,atol,mtol", [("bf16", 33, 0.24, 0.018), ("fp32", 17, 2e-3, 1e-4)])      # bf16: 1.5 x measured (0.13-0.16 / 0.012, profiles/r05_parity_measured.jsonl)
 def test_vq16_real_512_in_batch_chunks(prec, B, atol, mtol):
     """32x32 tokens -> 512x512 pixels through the real VQ-16 decoder; B is one more than the activation-chunk size
     (engine_vq.hip car_vq_decode: 32 images in bf16, 15-16 in fp32), the golden tokens sit in the first and the last chunk."""
@@ -135,6 +135,7 @@ def test_vq16_real_512_in_batch_chunks(prec, B, atol, mtol):
         p = px[row].cpu().numpy()
         for name, got in (("lattice", p[:, ::8, ::8]), ("corner", p[:, :24, :24]), ("centre", p[:, 244:268, 244:268])):
             d = np.abs(got - gold[name][gi])
+            record_measured(f"vq16_512[{prec},row{row},{name}]", max_abs_diff=d.max(), mean_abs_diff=d.mean())
             assert d.max() <= atol and d.mean() <= mtol, (prec, row, name, d.max(), d.mean())
     eng.close()
 

@@ -7,13 +7,13 @@ Contract:
   * fast mode (bf16): graded teacher-forced (reference bf16 is itself not thread-stable):
     per-step logits max|d| <= 0.6*k and mean|d| <= 0.08*k vs the fp32 reference (k = 1, or sqrt(s^2+(s-1)^2)
     under CFG scale s, because the mix u+(c-u)*s amplifies single-pass error); arg-max equal wherever the
-    reference top-2 margin > 0.25*k; pixels max|d| <= 0.5 / mean|d| <= 0.03 on the random-init decoder.
+    reference top-2 margin > 0.25*k; pixels max|d| <= 0.24 / mean|d| <= 0.018 on the random-init decoder (1.5 x measured).
 """
 import numpy as np
 import pytest
 import torch
 
-from tests.cases import CASES, load_case
+from tests.cases import record_measured, CASES, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -77,11 +77,13 @@ def test_fast_mode_teacher_forced(name):
     if "pixels" in gold:
         px = eng.vq_decode(forced, cs["H"] // 16, cs["W"] // 16).cpu().numpy()
         dp = np.abs(px - gold["pixels"])
-        assert dp.max() <= 0.5 and dp.mean() <= 0.03, (dp.max(), dp.mean())
+        record_measured(f"pixels_bf16[{name}]", max_abs_diff=dp.max(), mean_abs_diff=dp.mean())
+        # 1.5 x the deviation measured on MI355X (0.159 / 0.012, profiles/r05_parity_measured.jsonl; the reference's own bf16-vs-fp32 pixels: 0.132 / 0.0094)
+        assert dp.max() <= 0.24 and dp.mean() <= 0.018, (dp.max(), dp.mean())
     eng.close()
 
 
-@pytest.mark.parametrize("prec,atol,mtol", [("fp32", 2e-3, 1e-4), ("bf16", 0.6, 0.04)])
+@pytest.mark.parametrize("prec,atol,mtol", [("fp32", 2e-3, 1e-4), ("bf16", 0.24, 0.018)])      # bf16: 1.5 x measured (profiles/r05_parity_measured.jsonl)
 def test_vq16_real_architecture(prec, atol, mtol):
     """The real VQ-16 decoder (ch=128, z=256, 16384x8 codebook) on an 8x8 token grid vs the reference."""
     import os
@@ -95,6 +97,7 @@ def test_vq16_real_architecture(prec, atol, mtol):
     eng.load_state_dict(gsd); eng.load_state_dict(synth.vq_state_dict(cfg.vq, seed=2)); eng.finalize()
     px = eng.vq_decode(torch.from_numpy(gold["tokens"]), 8, 8).cpu().numpy()
     d = np.abs(px - gold["pixels"])
+    record_measured(f"vq16_8x8[{prec}]", max_abs_diff=d.max(), mean_abs_diff=d.mean())
     assert d.max() <= atol and d.mean() <= mtol, (d.max(), d.mean())
     eng.close()
 
