@@ -13,7 +13,7 @@ from collections import defaultdict
 fetch_csv, write_csv, steps, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 precision = sys.argv[6] if len(sys.argv) > 6 else "bf16"
 DEC = ("dec_gemm_kernel", "dec_attn2", "rmsnorm2_kernel", "sample_greedy_kernel", "sample_stochastic_kernel", "advance_kernel",
-       "dec_gemm_f32_kernel", "dec_attn_f32")      # exact mode (decode_f32.hip); its rmsnorm_kernel<float> is shared with the prefill and left out (< 0.5 % of the step's bytes)
+       "dec_gemm_f32_kernel", "dec_gemm_f32t_kernel", "dec_attn_f32")      # exact mode (decode_f32.hip); its rmsnorm_kernel<float> is shared with the prefill and left out (< 0.5 % of the step's bytes)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from controlar_amd import _lib
 build_id = _lib.load().car_build_id().decode()
