@@ -25,7 +25,9 @@ def _build(name, extra=()):
 def test_exact_mode_kernels_against_fp64_references():
     """decode_f32.hip (experiments/f32_check.hip, quick mode): dec_gemm_f32 on v_mfma_f32_16x16x4_f32 — every tile configuration and epilogue (plain, residual, SwiGLU,
     RoPE + q scale + K/V rows) within 2e-5 of an fp64 GEMM, bit-identical across tile configurations and between a row computed alone and inside a batch; the
-    fixed-split fp32 attention within 2e-5 of an fp64 softmax(QK^T)V over masked / ragged prefixes at four positions and four batch sizes, bit-identical alone vs in a batch."""
+    fixed-split fp32 attention within 2e-5 of an fp64 softmax(QK^T)V over masked / ragged prefixes at four positions and four batch sizes, bit-identical alone vs in a batch.
+    Round 5: the LDS-tiled kernel dec_gemm_f32t (ten configurations: 1 / 2 / 4 / 8 K-groups, both stage depths) BIT-equal to the register kernel on every epilogue, plain and
+    with the on-the-fly RMSNorm (itself within 2e-4 of an fp64 norm + GEMM); the one-launch attention forms (4-, 12-, 16-wave workgroups) bit-equal to split + combine."""
     exe = _build("f32_check")
     out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout[-3000:] + out.stderr[-1000:]
