@@ -275,10 +275,19 @@ def main():
 
     def build_and_export():
         build_only()
-        os.makedirs(cdir, exist_ok=True)
-        for e_, f_ in ((eng, pk[0]), (vq_eng, pk[1])):
-            e_._check(e_.lib.car_export_packed(e_._h, (f_ + f".tmp{os.getpid()}").encode()), "car_export_packed")
-            os.replace(f_ + f".tmp{os.getpid()}", f_)
+        try:        # a failed export (no space under the cache directory, ...) must not take rank 0 down: the other ranks then fail to import and build for themselves
+            os.makedirs(cdir, exist_ok=True)
+            for e_, f_ in ((eng, pk[0]), (vq_eng, pk[1])):
+                e_._check(e_.lib.car_export_packed(e_._h, (f_ + f".tmp{os.getpid()}").encode()), "car_export_packed")
+                os.replace(f_ + f".tmp{os.getpid()}", f_)
+        except Exception as ex:
+            log(f"packed-image export failed ({ex!r}): every rank builds its own weights")
+            for f_ in pk:
+                for g_ in (f_, f_ + f".tmp{os.getpid()}"):
+                    try:
+                        os.remove(g_)
+                    except OSError:
+                        pass
 
     def import_packed():
         for e_, f_ in ((eng, pk[0]), (vq_eng, pk[1])):
