@@ -346,8 +346,8 @@ def main():
     # car_generate then has no host wait at all)
     first_valid = None
     if not c2i:
-        nz = mask != 0
-        first_valid = int(torch.where(nz.any(dim=1), nz.to(torch.int64).argmax(dim=1), torch.full((mask.shape[0],), T, device=mask.device)).min())
+        from controlar_amd.engine import first_valid_position
+        first_valid = first_valid_position(mask)
     labels = None
     if c2i:
         labels = torch.stack([synth.class_labels(1, cfg.gpt.num_classes, seed=1234 + rank + world * j)[0] for j in range(args.batch)]).to(dev)

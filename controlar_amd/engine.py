@@ -24,6 +24,16 @@ def _dt(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported tensor dtype {t.dtype} (float32 or bfloat16)")
 
 
+def first_valid_position(emb_masks: torch.Tensor) -> int:
+    """First attendable prompt position over a batch of LEFT-padded caption masks [B, T] (sample_t2i.py:146-160): min over the rows of the index of the first
+    non-zero entry; a row without any valid token counts as T.  This is what `car_sampling.first_valid_hint - 1` carries: the prefill window of car_generate
+    starts at the multiple of 16 at or below it.  One reduction — free on a host mask, one sync on a device mask (do it once, outside a timed loop)."""
+    B, T = emb_masks.shape
+    nz = emb_masks != 0
+    first = torch.where(nz.any(dim=1), nz.to(torch.int64).argmax(dim=1), torch.full((B,), T, device=emb_masks.device))
+    return int(first.min())
+
+
 class Engine:
     """One context = one set of weights in one arithmetic mode ('fp32' exact | 'bf16' fast)."""
 
@@ -151,8 +161,7 @@ class Engine:
         if emb_masks is not None:
             assert emb_masks.shape[0] == B and emb_masks.shape[-1] == T          # generate.py:185-186
             if first_valid is None and emb_masks.device.type == "cpu" and emb_masks.numel():
-                nz = emb_masks.reshape(B, T) != 0
-                first_valid = int(torch.where(nz.any(dim=1), nz.to(torch.int64).argmax(dim=1), torch.full((B,), T)).min())
+                first_valid = first_valid_position(emb_masks.reshape(B, T))
             mask_t = emb_masks.to(device=self.device, dtype=torch.int64).contiguous()
         sp = L.CarSampling()
         sp.first_valid_hint = 0 if (first_valid is None or emb_masks is None) else max(0, min(int(first_valid), T)) + 1

@@ -83,3 +83,18 @@ def test_bench_refuses_library_switches(monkeypatch):
     monkeypatch.setenv("CAR_NO_GRAPH", "1")
     with pytest.raises(SystemExit, match="CAR_NO_GRAPH"):
         bench.refuse_debug_environment()
+
+
+def test_first_valid_position_of_left_padded_masks():
+    """The host-side value behind car_sampling.first_valid_hint: min over the batch of the first non-zero mask column; an all-pad row counts as T."""
+    from controlar_amd.engine import first_valid_position
+    _, mask = synth.text_embeddings_with_lengths([9, 60, 120, 1], 120, 8)
+    assert first_valid_position(mask) == 0                       # the unpadded prompt
+    assert first_valid_position(mask[:2]) == 60                  # T - 60
+    assert first_valid_position(mask[[0, 3]]) == 111             # T - 9
+    assert first_valid_position(mask[3:]) == 119
+    assert first_valid_position(torch.zeros(2, 120, dtype=torch.int64)) == 120
+    m = torch.zeros(1, 120, dtype=torch.int64); m[0, 40] = 1; m[0, 100:] = 1      # a hole in the mask: the first valid column counts
+    assert first_valid_position(m) == 40
+    _, masks = synth.text_embeddings(64, 120, 8)
+    assert first_valid_position(masks) == 120 - int(masks.sum(dim=1).max())
