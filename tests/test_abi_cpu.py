@@ -217,3 +217,18 @@ def test_exact_mode_tile_choice_and_norm_partials_are_valid_for_every_model_size
                 I = pick(M, N, K, 1) // 100
                 partials = N // (16 * (2 if I >= 2 else 1))
                 assert partials % 4 == 0 and 0 < partials <= 128, (dim, M, N, K, I, partials)
+
+
+def test_shipped_library_contains_no_debug_switches():
+    """The A/B and profiling switches (CAR_* environment variables) are compiled out of libcontrolar_hip.so (csrc/car_common.h CAR_KNOB, csrc/build.sh): no getenv
+    import, no switch name among its strings; the development build next to it has them."""
+    import subprocess
+    def names(path):
+        data = open(path, "rb").read()
+        return set(m.decode() for m in re.findall(rb"CAR_[A-Z0-9_]{3,}", data))
+    rel, dev = names(L.LIB_PATH), names(L.DEV_LIB_PATH)
+    allowed = {"CAR_F32", "CAR_BF16"}                       # mode names inside error messages
+    assert rel <= allowed, sorted(rel - allowed)
+    assert {"CAR_NO_GRAPH", "CAR_DEBUG_SKIP_STEPS", "CAR_CHAINS"} <= dev
+    syms = subprocess.run(["nm", "-D", L.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
