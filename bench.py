@@ -76,6 +76,14 @@ def parse():
                     help="headline configuration on one GPU only: after the timed region, time this many steps (+ 1 warm-up) of the BIT-IDENTICAL mode (`--precision fp32`, 384 "
                          "images) in a child process and report it as the `exact` block of the same JSON line — north_star asks for >= 20 images/s WITH the reference's greedy "
                          "tokens; the bf16 headline is tolerance-graded, this leg is the one whose tokens are compared with the reference's.  0 = skip")
+    ap.add_argument("--config-legs", default="2,3,5,4,1",
+                    help="headline configuration on one GPU only: after the exact leg, time these BASELINE configs (`--config N`, 1 warm-up + --config-leg-steps steps each) in child "
+                         "processes and report them as the `configs` block of the same JSON line, so that the driver's record carries every BASELINE config, not only the headline.  '' = skip")
+    ap.add_argument("--config-leg-steps", type=int, default=2)
+    ap.add_argument("--legs-budget-s", type=float, default=420.0, help="stop starting further config legs once this much wall clock has gone into them")
+    ap.add_argument("--pack-cache", action="store_true",
+                    help="N = 1: restore the packed weight images from the bench cache directory if this exact configuration was exported there (by the headline run of the same "
+                         "build), else build and export — the config legs use it so that a leg on the headline's model does not re-synthesise 750 M parameters")
     ap.add_argument("--fp8-weight-only", action="store_true", help="--config 5: weight-only e4m3 (bf16 MFMA) instead of the W8A8 form BASELINE names; reported as a variant by the default --config 5 run")
     ap.add_argument("--no-variants", action="store_true", help="skip the child-process legs (exact block, config-5 variant)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
@@ -207,6 +215,24 @@ def cpu_baseline(cfg, gsd, vsd, H, W, n_tok_sample):
     return out
 
 
+def pack_cache_dir():
+    """Directory of the packed-weight images shared by the ranks of one node / the legs of one run: private to this user (mode 0700, ownership checked —
+    ADVICE r5: a predictable world-writable path would let another local user plant images); anything else falls back to a fresh private directory."""
+    import stat
+    import tempfile
+    d = os.environ.get("CONTROLAR_PACK_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"controlar_amd_bench_{os.getuid()}"))
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st_ = os.stat(d)
+        if st_.st_uid != os.getuid() or (st_.st_mode & 0o022) or not stat.S_ISDIR(st_.st_mode):
+            raise PermissionError(f"{d}: not a private directory of uid {os.getuid()}")
+        return d
+    except Exception as ex:
+        d2 = tempfile.mkdtemp(prefix="controlar_amd_bench_")
+        log(f"pack cache: {ex!r}; using {d2}")
+        return d2
+
+
 def child_leg(extra, timeout=900):
     """One more bench configuration in a child process (its own HIP contexts: the parent has released its device memory), returns its parsed JSON line or an error."""
     import subprocess
@@ -269,14 +295,16 @@ def main():
     # plain copies) — eight ranks each spending 11 s of host synthesis on one shared host is start-up time, not work (dist.load_weights_once)
     import hashlib
     from controlar_amd.dist import load_weights_once
-    tag = hashlib.blake2b((repr(bytes(eng._cc)) + repr(bytes(vq_eng._cc)) + args.precision + args.vq_precision + eng.lib.car_build_id().decode()).encode(), digest_size=8).hexdigest()
-    cdir = os.environ.get("CONTROLAR_PACK_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"controlar_amd_bench_{os.getuid()}"))
+    # the tag covers everything the packed images depend on: the two car_config blocks, the arithmetic, the library build AND the generator of the synthetic weights
+    # (a synth.py change with no csrc change must not find stale images)
+    synth_src = open(synth.__file__, "rb").read()
+    tag = hashlib.blake2b((repr(bytes(eng._cc)) + repr(bytes(vq_eng._cc)) + args.precision + args.vq_precision + eng.lib.car_build_id().decode()).encode() + synth_src, digest_size=8).hexdigest()
+    cdir = pack_cache_dir()
     pk = [os.path.join(cdir, f"synth0_{tag}_{k}.carpk") for k in ("gpt", "vq")]
 
     def build_and_export():
         build_only()
         try:        # a failed export (no space under the cache directory, ...) must not take rank 0 down: the other ranks then fail to import and build for themselves
-            os.makedirs(cdir, exist_ok=True)
             for e_, f_ in ((eng, pk[0]), (vq_eng, pk[1])):
                 e_._check(e_.lib.car_export_packed(e_._h, (f_ + f".tmp{os.getpid()}").encode()), "car_export_packed")
                 os.replace(f_ + f".tmp{os.getpid()}", f_)
@@ -292,7 +320,20 @@ def main():
     def import_packed():
         for e_, f_ in ((eng, pk[0]), (vq_eng, pk[1])):
             e_._check(e_.lib.car_import_packed(e_._h, f_.encode()), "car_import_packed")
-    how = load_weights_once(dist, rank, pk, build_and_export, import_packed, build_only)
+    legs = [int(x) for x in args.config_legs.split(",") if x.strip()] if (world == 1 and not args.no_variants and args.config == 0 and args.precision == "bf16" and args.model == "xl"
+                                                                        and args.batch == 768 and not args.weights_fp8 and not args.kv_fp8 and not args.sample_logits) else []
+    if world == 1 and (args.pack_cache or legs):
+        # one GPU: a config leg restores the images the headline run exported (same model, same build); the headline exports when legs will follow
+        how = None
+        if args.pack_cache and all(os.path.exists(f) for f in pk):
+            try:
+                import_packed(); how = "imported"
+            except Exception as ex:
+                log(f"packed-image import failed ({ex!r}): building")
+        if how is None:
+            build_and_export(); how = "built"
+    else:
+        how = load_weights_once(dist, rank, pk, build_and_export, import_packed, build_only)
     gsd, vsd = sds.get("g"), sds.get("v")                   # None on a rank that imported the packed images (only rank 0 at N = 1 needs them: the CPU baseline)
     side = torch.cuda.Stream(device=dev)
     log(f"weights ready ({how})")
@@ -519,10 +560,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, gsd, vsd, Hh, Ww, args.cpu_tokens)
         headline = (args.config == 0 and args.precision == "bf16" and args.model == "xl" and (Hh, Ww) == (512, 512) and not args.weights_fp8 and not args.kv_fp8
                     and not args.sample_logits and args.cfg_scale <= 1.0)
-        if world == 1 and not args.no_variants and ((headline and args.exact_leg_steps > 0) or (args.config == 5 and args.fp8_mfma)):
+        if world == 1 and not args.no_variants and ((headline and (args.exact_leg_steps > 0 or legs)) or (args.config == 5 and args.fp8_mfma)):
             eng.close(); vq_eng.close(); del img, emb, mask, toks, px
             torch.cuda.empty_cache()
-            if headline:
+            if headline and args.exact_leg_steps > 0:
                 log("exact leg (child process): --precision fp32, bit-identical tokens")
                 ex = child_leg(["--precision", "fp32", "--steps", str(args.exact_leg_steps), "--warmup", "1"])
                 if "error" in ex:
@@ -536,7 +577,26 @@ def main():
                                     "workload": ex["config"]["workload"],
                                     "note": "same workload as the headline in the mode whose greedy tokens are bit-identical to the fp32 CPU reference (row 0 = the committed "
                                             "reference golden tests/golden/xl_canny_512_cfg1.npz: agreement must be 1.0); timed in a child process after the headline's timed region"}
-            else:
+            if headline and legs:
+                # every other BASELINE config, driver-timed: one child process each (its own contexts), the same harness and JSON contract as `--config N`
+                out["configs"] = {}
+                t_legs = time.perf_counter()
+                for cno in legs:
+                    if time.perf_counter() - t_legs > args.legs_budget_s:
+                        out["configs"][str(cno)] = {"skipped": f"leg budget of {args.legs_budget_s:.0f} s spent"}
+                        continue
+                    log(f"config {cno} leg (child process)")
+                    t_l0 = time.perf_counter()
+                    v = child_leg(["--config", str(cno), "--steps", str(args.config_leg_steps), "--warmup", "1", "--pack-cache"], timeout=600)
+                    if "error" in v:
+                        out["configs"][str(cno)] = v
+                        continue
+                    out["configs"][str(cno)] = {"value": v["value"], "unit": v["unit"], "per_gpu_images_per_sec": v["config"]["per_gpu_images_per_sec"], "ms_per_step": v["ms_per_step"],
+                                                "steps": v["steps"], "warmup": v["warmup"], "dtype": v["dtype"], "images_per_gpu": v["config"]["images_per_gpu"], "cfg_scale": v["config"]["cfg_scale"],
+                                                "decode_ms_per_token": v["roofline"]["avg_launch_ms"], "roofline": {k_: v["roofline"][k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_ms")},
+                                                "decode_kernels_per_step": v["config"]["decode_kernels_per_step"], "stage_ms": v["config"].get("stage_ms"), "weights": v["config"]["weights"],
+                                                "workload": v["config"]["workload"], "leg_wall_s": time.perf_counter() - t_l0}
+            if not headline:
                 log("config 5 variant (child process): weight-only e4m3 on the bf16 MFMA")
                 v = child_leg(["--config", "5", "--fp8-weight-only", "--steps", str(args.steps), "--warmup", str(args.warmup)])
                 out["config"]["variants"] = {"this_line": "W8A8: e4m3 weights x e4m3 activations on v_mfma_f32_16x16x32_fp8_fp8 (BASELINE configs[4] as named)",

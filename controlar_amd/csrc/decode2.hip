@@ -51,6 +51,109 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {          // v_cvt_pk_
 #define STAMP(p, i) do { } while (0)
 #endif
 
+// A decode kernel's parameter block is 150-300 bytes = 3-5 cache lines of the kernarg segment.  hipcc places each s_load next to its first use with an
+// s_waitcnt in front of the next, so a cold kernel start walked the lines one scalar-cache miss after the other (five dependent misses in dec_gemm's prologue:
+// ISA of round 5).  Touch every line up front — independent s_loads, one wait — and the later field loads hit the scalar cache.
+template <int NLINES>
+__device__ __forceinline__ void car_kernarg_prefetch() {
+    const __attribute__((address_space(4))) unsigned* ka = (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t[NLINES];
+#pragma unroll
+    for (int i = 0; i < NLINES; ++i) t[i] = ka[i * 16];
+#pragma unroll
+    for (int i = 0; i < NLINES; ++i) asm volatile("" ::"s"(t[i]));
+}
+
+// L2 run-ahead helper (decode2_params.h CAR_PF_FIELDS): workgroup `hidx` of `pf_wgs` helpers touches one dword per 128-byte line of its XCD's eighth of up to two
+// tensors, U lines per lane in flight.  Plain loads (default cache policy: the consumers' non-temporal loads hit the lines); nothing is stored.
+__device__ inline void car_pf_helper(const void* p0, unsigned b0, const void* p1, unsigned b1, int hidx, int pf_wgs) {
+    const int x = (int)(blockIdx.x & 7), R = pf_wgs >> 3, r = hidx >> 3, nth = (int)blockDim.x, tid = (int)threadIdx.x;
+    if (r >= R) return;
+    unsigned acc = 0;
+#pragma unroll
+    for (int job = 0; job < 2; ++job) {
+        const unsigned* q = (const unsigned*)(job ? p1 : p0);
+        const unsigned lines = (job ? b1 : b0) >> 7;
+        if (!q || !lines) continue;
+        const unsigned per = (lines + 7) >> 3, lo = (unsigned)x * per, hi = lo + per < lines ? lo + per : lines;
+        const unsigned step = (unsigned)(R * nth);
+        for (unsigned i = lo + (unsigned)(r * nth + tid); i < hi; i += step * 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const unsigned j = i + (unsigned)u * step; v[u] = 0; if (j < hi) v[u] = q[(size_t)j * 32]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u];
+        }
+    }
+    asm volatile("" ::"v"(acc));          // keeps the loads alive
+}
+
+// ---------------------------------------------------------------------------------------------- early launch (decode2_params.h CAR_HS_FIELDS)
+// Compiled in only with -DCAR_EARLY_LAUNCH (experiments/lat_probe): in the product build HS_FRESH / HS_WT are the constant false and the loads / stores below are plain.
+#ifdef CAR_EARLY_LAUNCH
+#define HS_FRESH(p) ((p).dep != nullptr)
+#define HS_WT(p) ((p).done != nullptr)
+#define HS_WAIT(p) car_hs_wait((p).dep, (p).dep_n, (p).hs_err)
+#define HS_ARRIVE(p) car_hs_arrive((p).done)
+#else
+#define HS_FRESH(p) false
+#define HS_WT(p) false
+#define HS_WAIT(p) do { } while (0)
+#define HS_ARRIVE(p) do { } while (0)
+#endif
+typedef unsigned long long u64_t;
+__device__ __forceinline__ u64_t car_ld8_agent(const void* q) { return __hip_atomic_load((const u64_t*)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16 bytes the predecessor kernel wrote (fresh != 0: two 8-byte agent-scope loads) or anything older (a plain 16-byte load)
+__device__ __forceinline__ u32x4 car_ld16(const void* q, bool fresh) {
+    if (!fresh) return *(const u32x4*)q;
+    const u64_t a = car_ld8_agent(q), b = car_ld8_agent((const char*)q + 8);
+    u32x4 r; r[0] = (unsigned)a; r[1] = (unsigned)(a >> 32); r[2] = (unsigned)b; r[3] = (unsigned)(b >> 32);
+    return r;
+}
+__device__ __forceinline__ uint2 car_ld8(const void* q, bool fresh) {
+    if (!fresh) return *(const uint2*)q;
+    const u64_t a = car_ld8_agent(q); uint2 r; r.x = (unsigned)a; r.y = (unsigned)(a >> 32); return r;
+}
+// stores of what the SUCCESSOR kernel reads: write-through agent-scope atomics when it may already be running (wt), plain stores otherwise
+__device__ __forceinline__ void car_st8(void* q, uint2 v, bool wt) {
+    if (wt) __hip_atomic_store((u64_t*)q, ((u64_t)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(uint2*)q = v;
+}
+__device__ __forceinline__ void car_st4(void* q, unsigned v, bool wt) {
+    if (wt) __hip_atomic_store((unsigned*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(unsigned*)q = v;
+}
+__device__ __forceinline__ void car_st2(void* q, bf16_t v, bool wt) {
+    if (wt) __hip_atomic_store((unsigned short*)q, (unsigned short)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(bf16_t*)q = v;
+}
+__device__ __forceinline__ void car_st1(void* q, unsigned char v, bool wt) {
+    if (wt) __hip_atomic_store((unsigned char*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(unsigned char*)q = v;
+}
+// Whole workgroup: returns once every workgroup of the predecessor has arrived (or the schedule is declared dead).  One wave polls: lanes 0-7 the eight shard
+// counters, lane 8 the sticky error word.  Bounded: ~2^17 polls (~0.1 s) then the error word is set and every later wait in the step returns at once.
+__device__ __forceinline__ void car_hs_wait(const unsigned* dep, int dep_n, unsigned* err) {
+    if (!dep) return;
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        const unsigned need = lane < 8 ? (unsigned)((dep_n + 7 - lane) >> 3) : 0u;
+        for (unsigned spins = 0;; ++spins) {
+            unsigned v = 0;
+            if (lane < 8) v = __hip_atomic_load(dep + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (lane == 8) v = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = lane < 8 ? v >= need : true, dead = lane == 8 && v != 0u;
+            if (__all(ok) || __any(dead)) break;
+            if (spins > (1u << 17)) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+}
+// Whole workgroup, after its last store: every wave drains, the workgroup meets, one lane arrives on its shard.
+__device__ __forceinline__ void car_hs_arrive(unsigned* done) {
+    if (!done) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(done + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // OCP e4m3fn has no infinity: values beyond +-448 must saturate BEFORE the conversion (the oracle's kv_fp8 model and include/controlar_hip.h say
 // clamp(-448, 448); an unclamped outlier would be stored as NaN and poison every later attention step of the sequence, since P * NaN = NaN even at P = 0)
 __device__ inline float sat448(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
@@ -93,7 +196,14 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     bf16_t* xs = (bf16_t*)red_all;
     float* red = NORM == 1 ? red_all + (16 * xs_ld) / 2 : red_all;
     constexpr int XPU = F8 ? 2 : 1;                                    // X chunks (k-blocks) per weight load unit
+    car_kernarg_prefetch<(sizeof(GemmDP) + 63 + 48) / 64>();           // the block + the hidden grid-size arguments behind it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.pf_wgs > 0 && (int)blockIdx.x >= (int)gridDim.x - p.pf_wgs) {      // L2 run-ahead helper (whole workgroup): no tile, no barrier
+        STAMP(p, 0);
+        car_pf_helper(p.pf_p0, p.pf_b0, p.pf_p1, p.pf_b1, (int)blockIdx.x - ((int)gridDim.x - p.pf_wgs), p.pf_wgs);
+        STAMP(p, 5);
+        return;
+    }
     // raised wave priority: when this kernel shares a CU with the other decode chain's attention waves (HBM-bound, thousands of them),
     // the instruction arbiter serves these few latency-bound waves first
     if (p.w_nt & 2) __builtin_amdgcn_s_setprio(3);
@@ -102,7 +212,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     const int MT = (Mb + J - 1) / J;
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of tiles —
     // the M tiles that share a weight row-block then hit the same L2
-    int t = blockIdx.x; const int total = gridDim.x;
+    int t = blockIdx.x; const int total = (int)gridDim.x - p.pf_wgs;
     if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
     const int nt = t / MT, mt = t - nt * MT;
     const int rb0 = nt * I, mb0 = mt * J;
@@ -121,32 +231,41 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     // keeps outstanding, not by MFMA issue): ~28 KiB-chunks of operands per wave, within the register budget
     // (round 4 tried 14 / 9 stages for the narrow tiles — w2 at K = 3584 leaves 14 k-blocks to each of 8 waves: the main loop's 2.3 us moved into the issue
     //  phase and the kernel stayed at 5.6 us: 80 workgroups x 115 KB is bound by what one CU pulls, ~60 GB/s; profiles/r04_lat_probe_v2_rows2.txt)
-    constexpr int DEPTH = (28 / (I + J * XPU)) < 2 ? 2 : ((28 / (I + J * XPU)) > 6 ? 6 : (28 / (I + J * XPU)));
+    // 16-wave tiles (round 6: the 80-workgroup linears wo / w2 of a small chain — twice the waves pulling per CU): 8 stages, so that w2's 7 k-blocks per wave are all in flight at once
+    constexpr int DEPTH = WAVES == 16 ? 8 : ((28 / (I + J * XPU)) < 2 ? 2 : ((28 / (I + J * XPU)) > 6 ? 6 : (28 / (I + J * XPU))));
     u32x4 wr[DEPTH][I], xr[DEPTH][J * XPU], nr[DEPTH][NORM == 2 ? XPU : 1];
     // NORM == 2: X fragments are bf16 h rows read in place (row-major, ld = K: lane (c16, q4) takes 16 bytes of row m at k = 32 kb + 8 q4), normalised in registers
     const bf16_t* hrow[J]; bool hok[J]; float rstd[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) { const int m = (mb0 + j) * 16 + (lane & 15); hok[j] = NORM == 2 && m < p.M; hrow[j] = NORM == 2 ? p.nh_in + (long)(hok[j] ? m : 0) * p.K + (lane >> 4) * 8 : nullptr; rstd[j] = 0.f; }
-    auto load = [&](u32x4 (&w)[I], u32x4 (&x)[J * XPU], u32x4 (&nwf)[NORM == 2 ? XPU : 1], int ku) {
+    const bool hs_fresh = HS_FRESH(p);               // early launch: X / the residual rows / their statistics come from a kernel that may still be running
+    const bool hs_wt = HS_WT(p);                     // ... and this kernel's outputs are read by one that may already be
+    // a stage's operands in two halves: what does not depend on the predecessor (weights, norm weight) and what does (X)
+    auto loadW = [&](u32x4 (&w)[I], u32x4 (&nwf)[NORM == 2 ? XPU : 1], int ku) {
 #pragma unroll
         for (int i = 0; i < I; ++i) {
             const u32x4* a = wp + ((long)i * nku + ku) * 64;
             w[i] = (p.w_nt & 1) ? __builtin_nontemporal_load(a) : *a;
         }
+        if (NORM == 2) {
+#pragma unroll
+            for (int u = 0; u < XPU; ++u) nwf[u] = *(const u32x4*)(p.nw + (ku * XPU + u) * 32 + (lane >> 4) * 8);
+        }
+    };
+    auto loadX = [&](u32x4 (&x)[J * XPU], int ku) {
         if (NORM == 0) {
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (j < jn) x[j * XPU + u] = xp[((long)j * nkb + ku * XPU + u) * 64]; }
+                for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (j < jn) x[j * XPU + u] = car_ld16(xp + ((long)j * nkb + ku * XPU + u) * 64, hs_fresh); }
         } else if (NORM == 2) {
-#pragma unroll
-            for (int u = 0; u < XPU; ++u) nwf[u] = *(const u32x4*)(p.nw + (ku * XPU + u) * 32 + (lane >> 4) * 8);
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (hok[j]) x[j * XPU + u] = *(const u32x4*)(hrow[j] + (ku * XPU + u) * 32); }
+                for (int u = 0; u < XPU; ++u) x[j * XPU + u] = car_ld16(hrow[j] + (ku * XPU + u) * 32, hs_fresh);      // unconditional (rows >= M read row 0 and meet rstd = 0): a predicated load costs a branch and the compiler's vmcnt accounting
         }
     };
+    auto load = [&](u32x4 (&w)[I], u32x4 (&x)[J * XPU], u32x4 (&nwf)[NORM == 2 ? XPU : 1], int ku) { loadW(w, nwf, ku); loadX(x, ku); };
     const bf16_t* xl = xs + (lane & 15) * xs_ld + (lane >> 4) * 8;     // NORM == 1: this lane's row / k offset inside a k-block
     auto compute = [&](const u32x4 (&w)[I], u32x4 (&x)[J * XPU], const u32x4 (&nwf)[NORM == 2 ? XPU : 1], int ku) {
         if (NORM == 1) {
@@ -199,7 +318,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     // the prologue measured 5.2-6.6 us of an 8 us kernel (experiments/lat_probe, profiles/r04_lat_probe_before_rows2.txt); issued first, it costs one L2 round trip.
     uint2 nh[8], na[8], nwv[8];
     bool n_add = false;
-    if (NORM == 1) {
+    if (NORM == 1 && !HS_FRESH(p)) {          // (early launch: these go out behind the wait, below)
         const int D = p.K, ng = D >> 2;
         if (wave < p.M) {
             const int m = wave;
@@ -221,23 +340,84 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     float4 sv[(NORM == 2 && J <= 2) ? J : 1][8];
     auto ssq_issue = [&](float4 (&v)[8], int j) {
         const int np4 = p.ssq_np >> 2, q4n = lane >> 4;
-        const float4* sp = (const float4*)(p.ssq_in + (long)((mb0 + j) * 16 + (lane & 15)) * p.ssq_np);
+        // unconditional loads at clamped addresses, the out-of-range ones zeroed by a select afterwards (adding +0 leaves the fixed-order sum's bits alone).  Round 5's
+        // predicated form compiled to a branch per load and an s_waitcnt vmcnt(0) behind each of the first two: two serialised round trips in front of the weight stream.
+        const float4* sp = (const float4*)(p.ssq_in + (long)(hok[j] ? (mb0 + j) * 16 + (lane & 15) : 0) * p.ssq_np);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { v[t] = make_float4(0.f, 0.f, 0.f, 0.f); if (hok[j] && q4n + 4 * t < np4) v[t] = sp[q4n + 4 * t]; }
+        for (int t = 0; t < 8; ++t) {
+            const int ci = q4n + 4 * t;
+            if (4 * t < np4) { const u32x4 r = car_ld16(sp + (ci < np4 ? ci : np4 - 1), hs_fresh); v[t] = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])); }      // (wave-uniform bound)
+            else v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     auto ssq_finish = [&](const float4 (&v)[8], int j) {
         float sum = 0.f;
+        const int np4 = p.ssq_np >> 2, q4n = lane >> 4;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { sum += v[t].x; sum += v[t].y; sum += v[t].z; sum += v[t].w; }
+        for (int t = 0; t < 8; ++t) { const bool ok = hok[j] && q4n + 4 * t < np4; sum += ok ? v[t].x : 0.f; sum += ok ? v[t].y : 0.f; sum += ok ? v[t].z : 0.f; sum += ok ? v[t].w : 0.f; }
         sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
         rstd[j] = hok[j] ? rsqrtf(sum / p.K + p.neps) : 0.f;
     };
-    if (NORM == 2) {
+    // Epilogue operands of this wave's FIRST epilogue unit (round 6): the residual values go out ahead of the weight stream, the RoPE row right behind it (its
+    // address needs *pos: a scalar load requested here, waited for only after the stages are in flight) — in round 5 the epilogue started two dependent round
+    // trips (pos -> rope row, or the residual load) after the fold.  Unconditional loads at clamped addresses; later units (u > wave) load in the loop as before.
+    // (Early launch: the residual stream was last written two kernels back — complete before this kernel was dispatched.)
+    constexpr int IPc = I >= 2 ? I / 2 : 1, IWc = I >= 2 ? 2 : 1;
+    const bool epi_first = wave < IPc * J;                               // wave-uniform
+    uint2 hv_h[IWc]; float4 cs_h[IWc];
+    int pos_h = 0;
+    if (EPI == EPI_QKV) pos_h = *(const __attribute__((address_space(4))) int*)(unsigned long long)p.pos;      // constant for the kernel's lifetime: read through the scalar cache (an s_load whose wait the compiler places at the first use)
+    if (EPI == EPI_RESID && epi_first) {
+        const int ip0 = wave / J, j0 = wave - ip0 * J;
+        int m0 = (mb0 + j0) * 16 + (lane & 15); m0 = m0 < p.M ? m0 : p.M - 1;
 #pragma unroll
-        for (int j = 0; j < J; ++j) { if (J <= 2) ssq_issue(sv[j], j); else { ssq_issue(sv[0], j); ssq_finish(sv[0], j); } }
+        for (int ii = 0; ii < IWc; ++ii) hv_h[ii] = *(const uint2*)(p.h + (long)m0 * p.N + (rb0 + ip0 * IWc + ii) * 16 + (lane >> 4) * 4);
     }
+    auto rope_first = [&]() {
+        if (EPI == EPI_QKV && epi_first) {
+            const int ip0 = wave / J;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) if (d < nkw) load(wr[d], xr[d], nr[d], ku_lo + d);
+            for (int ii = 0; ii < IWc; ++ii) {
+                const int n0 = (rb0 + ip0 * IWc + ii) * 16 + (lane >> 4) * 4, d0 = (n0 % p.dim) & 63;
+                cs_h[ii] = *(const float4*)(p.rope + ((long)pos_h * 32 + (d0 >> 1)) * 2);
+            }
+        }
+    };
+    if (hs_fresh) {
+        // ---- early launch: everything that does not depend on the predecessor first (weights of all stages, norm weight, RoPE row), then the wait, then X
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) if (d < nkw) loadW(wr[d], nr[d], ku_lo + d);
+        rope_first();
+        HS_WAIT(p);
+        if (NORM == 1) {
+            const int D = p.K, ng = D >> 2;
+            if (wave < p.M) {
+                const int m = wave;
+                const bf16_t* src = p.nidx ? p.nemb + (long)p.nidx[m] * D : p.nh_in + (long)m * D;
+                const bf16_t* add = p.nadd ? p.nctrl + ((long)m * p.n_tok + (*p.pos - p.nT + 1)) * D : nullptr;
+                n_add = add != nullptr;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int gi = lane + q * 64;
+                    if (gi < ng) { nh[q] = car_ld8(src + gi * 4, p.nidx == nullptr); nwv[q] = *(const uint2*)(p.nw + gi * 4); if (add) na[q] = *(const uint2*)(add + gi * 4); }
+                }
+            }
+        }
+        if (NORM == 2) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) { if (J <= 2) ssq_issue(sv[j], j); else { ssq_issue(sv[0], j); ssq_finish(sv[0], j); } }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) if (d < nkw) loadX(xr[d], ku_lo + d);
+    } else {
+        if (NORM == 2) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) { if (J <= 2) ssq_issue(sv[j], j); else { ssq_issue(sv[0], j); ssq_finish(sv[0], j); } }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) if (d < nkw) load(wr[d], xr[d], nr[d], ku_lo + d);
+        rope_first();
+    }
     if (NORM == 2 && J <= 2) {
 #pragma unroll
         for (int j = 0; j < J; ++j) ssq_finish(sv[J <= 2 ? j : 0], j);
@@ -253,7 +433,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int gi = lane + q * 64;
-                    if (gi < ng) { nh[q] = *(const uint2*)(src + gi * 4); if (add) na[q] = *(const uint2*)(add + gi * 4); }
+                    if (gi < ng) { nh[q] = car_ld8(src + gi * 4, hs_fresh && p.nidx == nullptr); if (add) na[q] = *(const uint2*)(add + gi * 4); }
                 }
             }
             float val[8][4];
@@ -325,6 +505,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     constexpr int IP = I >= 2 ? I / 2 : 1, IW = I >= 2 ? 2 : 1;
     const int q4 = lane >> 4, c16 = lane & 15;
     for (int u = wave; u < IP * J; u += WAVES) {
+        const bool first_u = u == wave;                                  // this unit's residual / RoPE operands were requested in the prologue
         const int ip = u / J, j = u - ip * J;
         if (j >= jn) continue;
         const int m = (mb0 + j) * 16 + c16;
@@ -350,7 +531,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
             const int nkb2 = p.N >> 6;                                   // (N/2)/32
             const long off = ((((long)(m >> 4) * nkb2 + (hid >> 5)) * 64 + ((hid & 31) >> 3) * 16 + (m & 15)) << 3) + (hid & 7);
             uint2 o; o.x = pack_bf16x2(s[0], s[1]); o.y = pack_bf16x2(s[2], s[3]);
-            *(uint2*)(p.outp + off) = o;
+            car_st8(p.outp + off, o, hs_wt);
         } else {
             float ssq_acc = 0.f;
 #pragma unroll
@@ -362,19 +543,19 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                     *(float4*)(p.outf + (long)m * p.N + n0) = o;
                 } else if (EPI == EPI_RESID) {
                     bf16_t* hp = p.h + (long)m * p.N + n0;
-                    const uint2 hv = *(const uint2*)hp;
+                    const uint2 hv = first_u ? hv_h[ii] : *(const uint2*)hp;
                     const float h0 = __uint_as_float(hv.x << 16), h1 = __uint_as_float(hv.x & 0xffff0000u);
                     const float h2 = __uint_as_float(hv.y << 16), h3 = __uint_as_float(hv.y & 0xffff0000u);
                     uint2 o;
                     o.x = pack_bf16x2(h0 + bf2f(f2bf(a[0])), h1 + bf2f(f2bf(a[1])));
                     o.y = pack_bf16x2(h2 + bf2f(f2bf(a[2])), h3 + bf2f(f2bf(a[3])));
-                    *(uint2*)hp = o;
+                    car_st8(hp, o, hs_wt);
                     if (p.ssq_out) {       // the squares of the STORED residual values: the next RMSNorm's row sum, one partial per (row, pair of row-blocks)
                         const float s0 = __uint_as_float(o.x << 16), s1 = __uint_as_float(o.x & 0xffff0000u), s2 = __uint_as_float(o.y << 16), s3 = __uint_as_float(o.y & 0xffff0000u);
                         ssq_acc += s0 * s0; ssq_acc += s1 * s1; ssq_acc += s2 * s2; ssq_acc += s3 * s3;
                     }
                 } else {   // EPI_QKV
-                    const int pos = *p.pos;
+                    const int pos = pos_h;
                     const int sec = n0 / p.dim, within = n0 - sec * p.dim, hh = within >> 6, d0 = within & 63;
                     const float x0 = bf2f(f2bf(a[0])), x1 = bf2f(f2bf(a[1])), x2 = bf2f(f2bf(a[2])), x3 = bf2f(f2bf(a[3]));   // Linear output -> bf16
                     const long sb = ((long)m * p.H + hh) * p.SA * 64;
@@ -383,13 +564,13 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                         if (p.kv8) {
                             unsigned char* vb = (unsigned char*)p.vc + sb + (long)(pos >> 5) * 2048 + (d0 >> 5) * 1024 + ((qv * 16 + (d0 & 15)) << 4) + ((d0 >> 4) & 1) * 8 + ev;
                             const int e01 = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(x0), sat448(x1), 0, false), e23 = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(x2), sat448(x3), 0, false);
-                            vb[0] = (unsigned char)(e01 & 0xff); vb[16] = (unsigned char)((e01 >> 8) & 0xff); vb[32] = (unsigned char)(e23 & 0xff); vb[48] = (unsigned char)((e23 >> 8) & 0xff);
+                            car_st1(vb, (unsigned char)(e01 & 0xff), hs_wt); car_st1(vb + 16, (unsigned char)((e01 >> 8) & 0xff), hs_wt); car_st1(vb + 32, (unsigned char)(e23 & 0xff), hs_wt); car_st1(vb + 48, (unsigned char)((e23 >> 8) & 0xff), hs_wt);
                         } else {
                             bf16_t* vb = p.vc + sb + ((long)(pos >> 5) * 4 + (d0 >> 4)) * 512 + ((qv * 16 + (d0 & 15)) << 3) + ev;
-                            vb[0] = f2bf(x0); vb[8] = f2bf(x1); vb[16] = f2bf(x2); vb[24] = f2bf(x3);
+                            car_st2(vb, f2bf(x0), hs_wt); car_st2(vb + 8, f2bf(x1), hs_wt); car_st2(vb + 16, f2bf(x2), hs_wt); car_st2(vb + 24, f2bf(x3), hs_wt);
                         }
                     } else {
-                        const float4 cs = *(const float4*)(p.rope + ((long)pos * 32 + (d0 >> 1)) * 2);   // (cos, sin) of pairs d0/2, d0/2+1
+                        const float4 cs = first_u ? cs_h[ii] : *(const float4*)(p.rope + ((long)pos * 32 + (d0 >> 1)) * 2);   // (cos, sin) of pairs d0/2, d0/2+1
                         const float r0 = x0 * cs.x - x1 * cs.y, r1 = x1 * cs.x + x0 * cs.y;
                         const float r2 = x2 * cs.z - x3 * cs.w, r3 = x3 * cs.z + x2 * cs.w;
                         if (sec == 0) {
@@ -397,26 +578,27 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                             uint2 o;
                             o.x = pack_bf16x2(bf2f(f2bf(r0)) * 0.125f, bf2f(f2bf(r1)) * 0.125f);
                             o.y = pack_bf16x2(bf2f(f2bf(r2)) * 0.125f, bf2f(f2bf(r3)) * 0.125f);
-                            *(uint2*)(p.qout + ((long)m * p.H + hh) * 64 + d0) = o;
+                            car_st8(p.qout + ((long)m * p.H + hh) * 64 + d0, o, hs_wt);
                         } else if (p.kv8) {       // rotated k: bf16 round (the Linear -> RoPE rounding points), then e4m3
                             unsigned char* kb_ = (unsigned char*)p.kc + sb + (long)(pos >> 4) * 1024 + ((((d0 & 31) >> 3) * 16 + (pos & 15)) << 4) + (d0 >> 5) * 8 + (d0 & 7);
                             int e = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(bf2f(f2bf(r0))), sat448(bf2f(f2bf(r1))), 0, false);
                             e = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(bf2f(f2bf(r2))), sat448(bf2f(f2bf(r3))), e, true);
-                            *(unsigned*)kb_ = (unsigned)e;
+                            car_st4(kb_, (unsigned)e, hs_wt);
                         } else {
                             uint2 o; o.x = pack_bf16x2(r0, r1); o.y = pack_bf16x2(r2, r3);
                             bf16_t* kb_ = p.kc + sb + ((long)(pos >> 4) * 2 + (d0 >> 5)) * 512 + ((((d0 & 31) >> 3) * 16 + (pos & 15)) << 3) + (d0 & 7);
-                            *(uint2*)kb_ = o;
+                            car_st8(kb_, o, hs_wt);
                         }
                     }
                 }
             }
             if (EPI == EPI_RESID && p.ssq_out) {       // lanes (c16, q4 = 0..3) hold the 4-column pieces of row m: fold them in a fixed order, one store per row
                 ssq_acc += __shfl_xor(ssq_acc, 16, 64); ssq_acc += __shfl_xor(ssq_acc, 32, 64);
-                if (q4 == 0) p.ssq_out[(long)m * p.ssq_ld + (rb0 / IW + ip)] = ssq_acc;
+                if (q4 == 0) car_st4(p.ssq_out + (long)m * p.ssq_ld + (rb0 / IW + ip), __float_as_uint(ssq_acc), hs_wt);
             }
         }
     }
+    HS_ARRIVE(p);
 #ifdef CAR_STAMP
     __builtin_amdgcn_s_waitcnt(0); STAMP(p, 5);
 #endif
@@ -425,7 +607,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 template <int I, int J, int WAVES, int F8, int NORM>
 static void launch_gemm_ij(const GemmDP& p, int epi, hipStream_t st) {
     const int Mb = (p.M + 15) / 16, MT = (Mb + J - 1) / J, NT = p.N / (16 * I);
-    const dim3 g(NT * MT), b(WAVES * 64);
+    const dim3 g(NT * MT + (p.pf_wgs > 0 ? p.pf_wgs : 0)), b(WAVES * 64);
     const size_t sh = (size_t)WAVES * I * J * 64 * 16 + (NORM == 1 ? (size_t)16 * (p.K + 8) * 2 : 0);
     static size_t attr[4] = {0, 0, 0, 0};
 #define LG(E)                                                                                                                   \
@@ -474,6 +656,9 @@ extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStr
                    case I * 100 + J * 10 + 1: if (f8 == 2) launch_gemm_ij<I, J, 8, 2, 0>(*p, epi, st); else if (f8) launch_gemm_ij<I, J, 8, 1, 0>(*p, epi, st); else launch_gemm_ij<I, J, 8, 0, 0>(*p, epi, st); break;
         CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
 #undef CASE
+        // 16 waves per 16-row tile (round 6): the narrow linears of a small chain (wo, w2: N / 16 = 80 workgroups) are bound by what one CU pulls; 16 waves keep
+        // twice the bytes in flight per CU
+        case 112: if (f8 == 2) launch_gemm_ij<1, 1, 16, 2, 0>(*p, epi, st); else if (f8) launch_gemm_ij<1, 1, 16, 1, 0>(*p, epi, st); else launch_gemm_ij<1, 1, 16, 0, 0>(*p, epi, st); break;
         default: return -1;
     }
     return 0;
@@ -489,6 +674,7 @@ extern "C" int car_pick_gemm_cfg(int M, int N, int K, int epi) {
     else if (Mb >= 3) cfg = hugeN ? 441 : (wideN ? 241 : (longK ? 211 : 110));
     else if (Mb == 2) cfg = hugeN ? 421 : (wideN ? 221 : (longK ? 121 : 120));
     else cfg = hugeN ? 411 : (wideN ? 211 : 111);     // one m-block: 8 waves per tile everywhere (more bytes in flight per CU; one prologue-norm row per wave up to 8 rows)
+    if (Mb == 1 && epi == EPI_RESID && cfg == 111 && N / 16 <= 128) cfg = 112;      // <= 128 workgroups: 16 waves each (wo, w2)
     int I = cfg / 100;
     if (epi == EPI_SWIGLU && I < 2) I = 2;
     while (I > 1 && N % (16 * I)) I >>= 1;
@@ -505,6 +691,7 @@ extern "C" void car_launch_dec_gemm(const GemmDP* p, int epi, hipStream_t st) {
 template <int NWAVE, int PF, int KV8>
 __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     __shared__ float red[NWAVE][66];
+    car_kernarg_prefetch<(sizeof(Attn2P) + 63 + 48) / 64>();
     const int split = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
     STAMP(p, 0);
@@ -659,6 +846,166 @@ __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     }
     if (persist) __syncthreads();       // `red` is reused by the next item
     }
+    if (persist && p.pf_wgs > 0 && (int)blockIdx.x >= n_items) car_pf_helper(p.pf_p0, p.pf_b0, p.pf_p1, p.pf_b1, (int)blockIdx.x - n_items, p.pf_wgs);
+#ifdef CAR_STAMP
+    __builtin_amdgcn_s_waitcnt(0); STAMP(p, 5);
+#endif
+}
+
+// Small-batch attention (round 6; up to ~16 sequences: BASELINE configs 2, 4, 5): ONE 16-wave workgroup per (sequence, head) on a 1-D grid — items first, the L2
+// run-ahead helpers (decode2_params.h CAR_PF_FIELDS) behind them.  What the 16-wave form of dec_attn2_kernel spent its 4.2 us on at 2 sequences (round-5 ISA and
+// experiments/lat_probe): kernel arguments, then *pos, then q and jmin, then one K/V block per wave per round — four to five dependent round trips for a 160 KB stream.
+// Here every wave requests TWO 32-position blocks at once (blocks jb + w and jb + w + 16: a 1024-position cache is one round trip; longer caches reuse the two
+// register sets alternately) right behind the scalar loads of *pos and jmin[b]; q travels with the first block.  The arithmetic per block, the block -> wave
+// assignment and the merge order are those of dec_attn2_kernel<16, 0, KV8> with nsplit = 1: bit-identical results (experiments/kbench checks it).
+// Text-pad mask bytes only ever belong to a wave's FIRST block (launcher: T <= 512).
+template <int KV8>
+__global__ __launch_bounds__(1024) void dec_attn2s_kernel(Attn2P p) {
+    __shared__ float red[16][66];
+    car_kernarg_prefetch<(sizeof(Attn2P) + 63 + 48) / 64>();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
+    STAMP(p, 0);
+    const int n_items = p.n_seq * p.H;
+    if ((int)blockIdx.x >= n_items) {
+        car_pf_helper(p.pf_p0, p.pf_b0, p.pf_p1, p.pf_b1, (int)blockIdx.x - n_items, p.pf_wgs);
+#ifdef CAR_STAMP
+        __builtin_amdgcn_s_waitcnt(0); STAMP(p, 5);
+#endif
+        return;
+    }
+    const int h = (int)blockIdx.x % p.H, b = (int)blockIdx.x / p.H;
+    const int pos = *p.pos;
+    const unsigned char* mk = p.mask ? p.mask + (long)b * p.T : nullptr;
+    const int jmin = mk ? p.jmin[b] : 0;
+    const long sbase = ((long)b * p.H + h) * p.SA * 64;
+    const u32x4* Kp = KV8 ? (const u32x4*)((const unsigned char*)p.kc + sbase) + lane : (const u32x4*)(p.kc + sbase) + lane;
+    const u32x4* Vp = KV8 ? (const u32x4*)((const unsigned char*)p.vc + sbase) + lane : (const u32x4*)(p.vc + sbase) + lane;
+    const bf16_t* qp = p.q + ((long)b * p.H + h) * 64;
+    bf16x8 qf0, qf1;                                                    // loaded behind the K / V requests (and behind the early-launch wait: the predecessor writes q)
+    const int nblk = (pos >> 5) + 1;
+    const bool hs_fresh = HS_FRESH(p), hs_wt = HS_WT(p);
+    const int lastb = nblk - 1;                                         // the block that holds the new token's K / V row: written by the predecessor (wqkv)
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NL = KV8 ? 2 : 4;
+    auto loadkv = [&](u32x4 (&kr)[4], u32x4 (&vr)[4], int blk) {
+        if (hs_fresh && blk == lastb) {                                 // wave-uniform
+#pragma unroll
+            for (int i = 0; i < NL; ++i) kr[i] = car_ld16(Kp + ((long)blk * NL + i) * 64, true);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) vr[i] = car_ld16(Vp + ((long)blk * NL + i) * 64, true);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) kr[i] = __builtin_nontemporal_load(Kp + ((long)blk * NL + i) * 64);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) vr[i] = __builtin_nontemporal_load(Vp + ((long)blk * NL + i) * 64);
+        }
+    };
+    unsigned ma[8];
+    auto compute = [&](const u32x4 (&kr_)[4], const u32x4 (&vr_)[4], int blk, bool use_mk) {
+        u32x4 kr[4], vr[4];
+        if (KV8) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 a = fp8x8_to_bf16x8_(kr_[i][0], kr_[i][1]), c2 = fp8x8_to_bf16x8_(kr_[i][2], kr_[i][3]);
+                const bf16x8 v0 = fp8x8_to_bf16x8_(vr_[i][0], vr_[i][1]), v1 = fp8x8_to_bf16x8_(vr_[i][2], vr_[i][3]);
+                kr[2 * i] = *(const u32x4*)&a; kr[2 * i + 1] = *(const u32x4*)&c2; vr[2 * i] = *(const u32x4*)&v0; vr[2 * i + 1] = *(const u32x4*)&v1;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { kr[i] = kr_[i]; vr[i] = vr_[i]; }
+        }
+        f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[0], qf0, z4, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[1], qf1, s0, 0, 0, 0);
+        f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[2], qf0, z4, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&kr[3], qf1, s1, 0, 0, 0);
+        float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        const int jb = blk * 32 + q4 * 4;
+        if (use_mk || blk * 32 + 31 > pos) {                           // wave-uniform: a block that needs per-position masking
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = jb + (e < 4 ? e : 12 + e);
+                unsigned mv = 1u;
+                if (use_mk) mv = ma[e];
+                const bool ok = (j <= pos) & ((j >= p.T) | (mv != 0u));
+                sc[e] = ok ? sc[e] : -INFINITY;
+            }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx > -INFINITY) {                                           // wave-uniform: something attendable in this block
+            const float mn = fmaxf(m_run, mx), alpha = __expf(m_run - mn);
+            float pe[8], ps = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pe[e] = __expf(sc[e] - mn); ps += pe[e]; }
+            l_run = l_run * alpha + ps; m_run = mn;
+            u32x4 pu; pu[0] = pack_bf16x2(pe[0], pe[1]); pu[1] = pack_bf16x2(pe[2], pe[3]); pu[2] = pack_bf16x2(pe[4], pe[5]); pu[3] = pack_bf16x2(pe[6], pe[7]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&pu, *(const bf16x8*)&vr[d], o[d], 0, 0, 0);
+            }
+        }
+    };
+    {
+        u32x4 ka[4], va[4], kb2[4], vb2[4];
+        int cur = (jmin >> 5) + wave;                                   // block in register set A; set B holds cur + 16
+        const bool mk_a = mk != nullptr && cur * 32 < p.T && cur < nblk;   // wave-uniform
+        if (mk_a) {
+            const int jb = cur * 32 + q4 * 4;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ma[e] = mk[min(jb + (e < 4 ? e : 12 + e), p.T - 1)];
+        }
+        // early launch: the history blocks are requested BEFORE the wait (they were written by earlier steps), the block of the new row and q behind it
+        const bool a_pre = cur < nblk && !(hs_fresh && cur == lastb), b_pre = cur + 16 < nblk && !(hs_fresh && cur + 16 == lastb);
+        if (a_pre) loadkv(ka, va, cur);
+        if (b_pre) loadkv(kb2, vb2, cur + 16);
+        HS_WAIT(p);
+        { const u32x4 q0 = car_ld16(qp + q4 * 8, hs_fresh), q1 = car_ld16(qp + 32 + q4 * 8, hs_fresh); qf0 = *(const bf16x8*)&q0; qf1 = *(const bf16x8*)&q1; }
+        if (cur < nblk && !a_pre) loadkv(ka, va, cur);
+        if (cur + 16 < nblk && !b_pre) loadkv(kb2, vb2, cur + 16);
+        bool first = true;
+        while (cur < nblk) {
+            compute(ka, va, cur, first && mk_a);
+            first = false;
+            if (cur + 32 < nblk) loadkv(ka, va, cur + 32);
+            if (cur + 16 < nblk) { compute(kb2, vb2, cur + 16, false); if (cur + 48 < nblk) loadkv(kb2, vb2, cur + 48); }
+            cur += 32;
+        }
+    }
+#ifdef CAR_STAMP
+    asm volatile("s_nop 0" ::"v"(l_run)); STAMP(p, 3);
+#endif
+    // ---- merge (the statements of dec_attn2_kernel): every lane of a q-group holds the same l partial; o[d][*] rows are identical
+    float lt = l_run + __shfl_xor(l_run, 16, 64); lt += __shfl_xor(lt, 32, 64);
+    if (q4 == 0) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) red[wave][2 + d * 16 + c16] = o[d][0];
+    }
+    if (lane == 0) { red[wave][0] = m_run; red[wave][1] = lt; }
+    __syncthreads();
+    STAMP(p, 4);
+    if (tid < 64) {
+        float M = red[0][0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) M = fmaxf(M, red[w][0]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const float mm = red[w][0];
+            const float a = mm > -INFINITY ? __expf(mm - M) : 0.f;
+            L += red[w][1] * a; O += red[w][2 + tid] * a;
+        }
+        const int k = h * 64 + tid;
+        long off;
+        if (p.out_packed) off = ((((long)(b >> 4) * (p.dim >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (b & 15)) << 3) + (k & 7);
+        else off = (long)b * p.dim + k;
+        car_st2(p.out + off, f2bf(O / L), hs_wt);
+    }
+    HS_ARRIVE(p);
 #ifdef CAR_STAMP
     __builtin_amdgcn_s_waitcnt(0); STAMP(p, 5);
 #endif
@@ -725,8 +1072,16 @@ __global__ __launch_bounds__(64) void dec_attn2_combine_kernel(const float* part
 // lds_pad: bytes of (unused) dynamic LDS requested per workgroup — an occupancy cap: with two decode chains in flight the
 // attention of one chain must leave registers and wave slots on every CU for the other chain's GEMM workgroups
 extern "C" void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, int lds_pad, hipStream_t st) {
+    if (variant == 162 && p->nsplit == 1 && p->T <= 512 && (!p->mask || p->jmin)) {      // small-batch form: 1-D grid of (sequence, head) items + L2 run-ahead helpers
+        Attn2P q = *p; q.n_seq = b; q.pgrid = 0;
+        if (q.pf_wgs < 0 || ((b * q.H) & 7)) q.pf_wgs = 0;
+        const dim3 g(b * q.H + q.pf_wgs);
+        if (q.kv8) hipLaunchKernelGGL((dec_attn2s_kernel<1>), g, dim3(1024), 0, st, q); else hipLaunchKernelGGL((dec_attn2s_kernel<0>), g, dim3(1024), 0, st, q);
+        return;
+    }
+    if (variant == 162) variant = 160;
     const bool persist = p->n_seq > 0 && p->pgrid > 0 && p->nsplit == 1;
-    Attn2P q = *p; if (!persist) { q.n_seq = 0; q.pgrid = 0; }
+    Attn2P q = *p; if (!persist) { q.n_seq = 0; q.pgrid = 0; q.pf_wgs = 0; }
     p = &q;
     const dim3 g = persist ? dim3(q.pgrid, 1, 1) : dim3(p->H, b, p->nsplit);
     const size_t sh = (size_t)(lds_pad > 0 ? lds_pad : 0);
@@ -739,7 +1094,8 @@ extern "C" void car_launch_dec_attn2_var(const Attn2P* p, int b, int variant, in
         // without the combine kernel beats nsplit x 4 waves + combine (one dependent kernel less per layer, experiments/small_chain)
         case 80: LA(8, 0); break;
         case 81: LA(8, 1); break;
-        case 160: LA(16, 0); break;      // (the 16-wave prefetch form, variant 161, was measured slower in round 3 and is gone: two register sets do not fit 128 VGPRs)
+        case 160: LA(16, 0); break;
+        case 161: LA(16, 1); break;
         default: LA(4, 1); break;
     }
 #undef LA
@@ -794,9 +1150,12 @@ extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const
 // the sum of squares folds through wave shuffles in a fixed order.  Lane l owns column groups l, l+64, ... (4 columns each).
 template <int NQ>
 __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
+    car_kernarg_prefetch<(sizeof(Norm2P) + 63 + 48) / 64>();
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     STAMP(p, 0);
-    if (r >= rows) return;
+    const bool hs_fresh = HS_FRESH(p), hs_wt = HS_WT(p);
+    HS_WAIT(p);                                                            // early launch: the residual stream comes from the predecessor
+    if (r < rows) {
     const int lane = threadIdx.x & 63;
     const int D = p.D, ng = D >> 2;
     const bf16_t* src = p.idx ? p.emb + (long)p.idx[r] * D : p.h_in + r * D;
@@ -811,7 +1170,7 @@ __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
     for (int q = 0; q < NQ; ++q) {
         const int gi = lane + q * 64;
         if (gi < ng) {
-            const uint2 u = *(const uint2*)(src + gi * 4);
+            const uint2 u = car_ld8(src + gi * 4, hs_fresh && p.idx == nullptr);
             float v[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
             if (add) {
                 const uint2 a = *(const uint2*)(add + gi * 4);
@@ -833,7 +1192,7 @@ __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
         const int gi = lane + q * 64;
         if (gi < ng) {
             const int k = gi * 4;
-            if (p.h_out) { uint2 u; u.x = pack_bf16x2(val[q][0], val[q][1]); u.y = pack_bf16x2(val[q][2], val[q][3]); *(uint2*)(p.h_out + r * D + k) = u; }
+            if (p.h_out) { uint2 u; u.x = pack_bf16x2(val[q][0], val[q][1]); u.y = pack_bf16x2(val[q][2], val[q][3]); car_st8(p.h_out + r * D + k, u, hs_wt); }
             const uint2 wu = wreg[q];
             const float w[4] = {__uint_as_float(wu.x << 16), __uint_as_float(wu.x & 0xffff0000u), __uint_as_float(wu.y << 16), __uint_as_float(wu.y & 0xffff0000u)};
             float o[4];
@@ -841,9 +1200,11 @@ __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
             for (int e = 0; e < 4; ++e) o[e] = bf2f(f2bf(val[q][e] * rstd)) * w[e];
             uint2 u; u.x = pack_bf16x2(o[0], o[1]); u.y = pack_bf16x2(o[2], o[3]);
             const long off = ((((r >> 4) * nkb + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (r & 15)) << 3) + (k & 7);
-            *(uint2*)(p.xn + off) = u;
+            car_st8(p.xn + off, u, hs_wt);
         }
     }
+    }
+    HS_ARRIVE(p);
 #ifdef CAR_STAMP
     __builtin_amdgcn_s_waitcnt(0); STAMP(p, 5);
 #endif

@@ -13,6 +13,38 @@
 #endif
 enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 
+// L2 run-ahead (round 6; small chains).  Measured on MI355X (experiments/xk_cache, profiles/r06_xk_cache.txt): the per-XCD L2 (8 x 4 MB) SURVIVES a kernel
+// boundary — a region the same XCD read in the previous kernel streams at L2 speed (8 MB in ~0.1 us against 1.4 us from HBM; the 256 MB Infinity Cache only
+// buys 15-20 %).  A small-batch decode layer is five short dependent kernels, three of which (attention, wo, w2) occupy 40-80 of the 256 CUs.  Those kernels
+// carry `pf_wgs` extra HELPER workgroups at the end of their grid: a helper touches one dword per 128-byte line of the weight tensors the NEXT kernels will stream
+// (up to two tensors per launch), restricted to the eighth of each tensor that the consumer's workgroups on the helper's own XCD will read (dec_gemm's XCD-aware
+// tile order gives XCD x the contiguous row range x of 8; workgroup id % 8 = XCD is the observed placement — only speed depends on it).  The HBM stream of the
+// weights then runs under the latency-bound kernels on otherwise idle CUs, and the consumers read L2.
+#define CAR_PF_FIELDS const void* pf_p0; const void* pf_p1; unsigned pf_b0, pf_b1; int pf_wgs;
+
+// Early launch (round 6; small chains).  A small-batch decode layer is five short DEPENDENT kernels, and each spends 2-3 us between its dispatch and its first
+// MFMA on work that does not depend on its predecessor at all: fetching its arguments, address arithmetic, and streaming its WEIGHTS (profiles/r06_lat_probe_*).
+// The chain therefore alternates between two streams (two parallel branches of the step's graph): kernel i+1 is dispatched while kernel i runs, requests its
+// weights, and only then waits — in the kernel — for kernel i's workgroups to ARRIVE; kernel i+2 follows kernel i on the same stream, which bounds the run-ahead
+// to one kernel and keeps every grid resident (no deadlock: a waiting workgroup only ever waits for a kernel dispatched before it on the other stream or
+// already complete on its own).  The hand-off follows MI355X_MICROARCH.md "valid forms": the producer stores what its successor reads with 8-byte (or
+// narrower) agent-scope relaxed atomic stores (write-through), every wave drains (s_waitcnt vmcnt(0)), the workgroup meets at a barrier and one lane adds 1 to
+// the counter of its XCD shard (8 counters on 8 cache lines: 240 arrivals on one word serialise at ~12 ns each); the consumer's first wave polls the 8 counters
+// with relaxed agent-scope loads, the workgroup meets at a barrier, and everything the predecessor wrote is read with agent-scope atomic loads.  Data older
+// than the predecessor was complete before this kernel was dispatched (same-stream order) and is read as ever.
+//   dep      counters of the predecessor (8 shards x 32 ints) or null; dep_n = its number of arriving workgroups
+//   done     counters this kernel arrives on, or null
+//   hs_err   sticky word: a wait that gives up (bounded spin) sets it, every later wait returns at once — a broken schedule ends in wrong tokens and a loud
+//            error (engine_internal.h check_sticky), never in a hang
+// MEASURED AND NOT SHIPPED (profiles/r06_lat_probe_early_launch.txt): the hand-off chain (write-through drain -> barrier -> arrival -> poll -> barrier -> agent-scope
+// loads) costs as much as the launch gap + prologue it hides: 34.1 vs 36.0 us per layer at 2 rows, 39.4 vs 37.7 at 8.  A kernel boundary (1.5-1.9 us) stays the
+// cheapest all-to-all synchronisation on this chip, as MI355X_MICROARCH.md prices it.  The fields and the code exist only with -DCAR_EARLY_LAUNCH (experiments/lat_probe).
+#ifdef CAR_EARLY_LAUNCH
+#define CAR_HS_FIELDS const unsigned* dep; int dep_n; unsigned* done; unsigned* hs_err;
+#else
+#define CAR_HS_FIELDS
+#endif
+
 struct GemmDP {
     const bf16_t* W;      // packed [N/16][K/32][64][8]
     const bf16_t* X;      // packed [ceil(M/16)][K/32][64][8]
@@ -45,6 +77,8 @@ struct GemmDP {
     // EPI_RESID: if set, the epilogue also writes ssq_out[m * ssq_ld + pair] = sum of the squares of the h values it STORES in row m over its pair of
     // row-blocks (pair = row-block / 2; row-block itself for one-row-block tiles): ssq_ld = N / 32 (N / 16)
     float* ssq_out; int ssq_ld;
+    CAR_PF_FIELDS
+    CAR_HS_FIELDS
     CAR_STAMP_FIELDS
 };
 
@@ -60,6 +94,8 @@ struct Attn2P {
     int H, SA, T, dim, nsplit, out_packed;
     int kv8;                    // the caches hold e4m3 bytes (K8 / V8 layouts), widened to bf16 in registers
     int n_seq, pgrid;           // persistent form (nsplit == 1): n_seq > 0 sequences, a 1-D grid of pgrid workgroups walks the n_seq*H items
+    CAR_PF_FIELDS               // helpers need the 1-D (persistent) grid: pgrid = n_seq * H + pf_wgs
+    CAR_HS_FIELDS               // dec_attn2s_kernel only
     CAR_STAMP_FIELDS
 };
 
@@ -68,5 +104,6 @@ struct Norm2P {
     const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
     const bf16_t* ctrl; const int* pos; int add /* bit 0: add the control token, bit 1: raised wave priority */; int T; int n_tok; float cs;
     int D; float eps;
+    CAR_HS_FIELDS
     CAR_STAMP_FIELDS
 };

@@ -153,7 +153,15 @@ extern "C" int car_get_stats(car_ctx* c, car_stats* out) {
     }
     {   // the library's A/B / profiling switches are CAR_* environment variables: report how many are set (0 = the shipped schedule)
         // switches the library actually read as set while it enqueued the last generate (latched there): always 0 in the shipped build, which has no switches
-        const int n = c->knob_hits;
+        // switches read by car_encode_control / car_vq_decode / finalize, or read once into a static, were missed by a per-generate latch.  The development
+        // build therefore reports the larger of (a) the switches READ as set on any entry since the last car_get_stats and (b) the CAR_* names in the environment now.
+        int n = c->knob_hits;
+#ifdef CAR_DEV_KNOBS
+        n = __atomic_exchange_n(&g_car_knob_hits, 0, __ATOMIC_RELAXED);
+        if (c->knob_hits > n) n = c->knob_hits;
+        { extern char** environ; int e = 0; for (char** ev = environ; ev && *ev; ++ev) if (!strncmp(*ev, "CAR_", 4)) ++e; if (e > n) n = e; }
+        c->knob_hits = 0;
+#endif
         c->stats.dev_knobs_active = n;
     }
     *out = c->stats;

@@ -30,6 +30,23 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     int normx_max = 48; bool normx_j4 = false;
     { const char* ev = CAR_KNOB("CAR_NORMX_MAX"); if (ev) normx_max = atoi(ev); ev = CAR_KNOB("CAR_NORMX_J4"); if (ev) normx_j4 = atoi(ev) != 0; }
     int nk = 0, bad_cfg = 0;
+    // L2 run-ahead (round 6; chains of one m-block: BASELINE configs 2, 4, 5).  The per-XCD L2 survives a kernel boundary (experiments/xk_cache: a region the same XCD
+    // read one kernel earlier streams at L2 speed), and three of a small layer's five kernels — attention, wo, w2 — occupy 40-160 of the 256 CUs.  They carry HELPER
+    // workgroups that touch the weights of the kernels that follow, XCD by XCD (decode2_params.h CAR_PF_FIELDS):
+    //     attention -> wo + w1|w3 of this layer,   wo -> w2 of this layer,   w2 -> wqkv of the next layer (the last layer: the first 16 MB of the vocabulary projection)
+    // so that the HBM stream of a layer's 41 MB runs under its latency-bound kernels.  experiments/lat_probe, 2 rows, position 631: 35.1 -> 32.7 us per layer.
+    const bool runahead = b <= 16 && c->n_cu >= 128 && !CAR_KNOB("CAR_NO_RUNAHEAD");
+    auto wimg = [&](const std::string& wname, const void*& ptr, unsigned& bytes, size_t cap = (size_t)24 << 20) {
+        auto it = c->w.find(wname + (f8 ? "#pk8" : "#pk"));
+        if (it == c->w.end()) { ptr = nullptr; bytes = 0; return; }
+        ptr = it->second.p; bytes = (unsigned)std::min(it->second.bytes, cap);
+    };
+    auto helpers_for = [&](int main_wgs) -> int {      // helper workgroups beside `main_wgs` workgroups: fill the chip once, multiple of 8 (the helper's XCD arithmetic), at least 32
+        if (!runahead || (main_wgs & 7)) return 0;
+        int h = ((c->n_cu - main_wgs) / 8) * 8;
+        if (h > 192) h = 192;
+        return h >= 32 ? h : 0;
+    };
     // returns the number of sum-of-squares partials per row the kernel leaves in p.ssq_out (0 if it writes none)
     auto gemm = [&](const std::string& wname, const bf16_t* X, int N, int K, int epi, GemmDP gp_) -> int {
         GemmDP p = gp_;
@@ -41,6 +58,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         if (p.ssq_in && b > 48 && b <= 64 && normx_j4) cfg = ((epi == EPI_SWIGLU || N >= 6144) ? 200 : 100) + 40 + 1;
         const int I = cfg / 100, J = (cfg / 10) % 10, Mb = (b + 15) / 16;
         p.w_nt = ((Mb + J - 1) / J == 1 ? 1 : 0) | (prio ? 2 : 0);      // bit 0: non-temporal weight stream, bit 1: raised wave priority
+        if (p.pf_wgs > 0) { p.pf_wgs = helpers_for((N / (16 * I)) * ((Mb + J - 1) / J)); if (p.pf_wgs > 160) p.pf_wgs = 160; }      // (the caller marks the kernels that host helpers)
         if (p.ssq_out) p.ssq_ld = N / (16 * (I >= 2 ? 2 : 1));
         if (car_launch_dec_gemm_cfg(&p, epi, cfg, st)) bad_cfg = cfg;
         ++nk;
@@ -103,9 +121,15 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             ap.q = fb.q; ap.kc = kc; ap.vc = vc; ap.pos = gr.pos; ap.mask = maskb ? maskb + (size_t)b0 * T : nullptr; ap.jmin = jmin ? jmin + b0 : nullptr;
             ap.out = fb.att; ap.part = fb.attn_part; ap.H = Hn; ap.SA = SA; ap.T = T; ap.dim = D; ap.nsplit = nsplit; ap.out_packed = 1; ap.kv8 = g.kv_cache_fp8 ? 1 : 0;
             if (gr.attn_pgrid > 0 && nsplit == 1) { ap.n_seq = b; ap.pgrid = gr.attn_pgrid; }
+            if (gr.attn_variant == 162) {      // the small-batch kernel hosts the run-ahead for wo and w1|w3
+                ap.pf_wgs = helpers_for(b * Hn);
+                if (ap.pf_wgs > 0) { wimg(L + "attention.wo.weight", ap.pf_p0, ap.pf_b0); wimg(L + "feed_forward.w13.weight", ap.pf_p1, ap.pf_b1); }
+            }
             car_launch_dec_attn2_var(&ap, b, gr.attn_variant, gr.attn_lds_pad, st); nk += nsplit > 1 ? 2 : 1;
         }
-        { GemmDP q = z; q.h = hc; if (normx) q.ssq_out = fb.ssq; ssq_np = gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
+        { GemmDP q = z; q.h = hc; if (normx) q.ssq_out = fb.ssq;
+          if (runahead) { q.pf_wgs = 1; wimg(L + "feed_forward.w2.weight", q.pf_p0, q.pf_b0); }
+          ssq_np = gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
         const bool nx2 = normx && ssq_np > 0;
         if (!nx2 && !fuse_norm) {
             Norm2P np; memset(&np, 0, sizeof(np));
@@ -118,6 +142,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         {   // w2 leaves the sums of squares for the next layer's first norm (or the final norm) unless that layer adds a control token first
             const bool next_special = l + 1 < g.n_layer && use_ctrl && (l + 1) % li == 0 && (l + 1) / li < 3;
             GemmDP q = z; q.h = hc; if (normx && !next_special) q.ssq_out = fb.ssq;
+            if (runahead) { q.pf_wgs = 1; wimg(l + 1 < g.n_layer ? "layers." + std::to_string(l + 1) + ".attention.wqkv.weight" : std::string("output.weight"), q.pf_p0, q.pf_b0, (size_t)16 << 20); }
             ssq_np = gemm(L + "feed_forward.w2.weight", fb.mid, D, Fh, EPI_RESID, q);
         }
     }
@@ -232,8 +257,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
                          float* logits_out, void* stream_) {
     if (check_sticky(c)) return -1;
 #ifdef CAR_DEV_KNOBS
-    g_car_knob_hits = 0;      // every switch read below (and by the kernels' launchers) counts into car_stats.dev_knobs_active of this call
-    struct KnobLatch { car_ctx* c; ~KnobLatch() { c->knob_hits = g_car_knob_hits; } } knob_latch{c};
+    // every switch read below (and by the kernels' launchers) counts into car_stats.dev_knobs_active; the counter runs across ALL entry points and is cleared by car_get_stats
+    struct KnobLatch { car_ctx* c; int at_entry; ~KnobLatch() { const int d = g_car_knob_hits - at_entry; if (d > c->knob_hits) c->knob_hits = d; } } knob_latch{c, g_car_knob_hits};
 #endif
     if (!c->finalized) FAIL(c, "car_generate: call car_finalize_weights first");
     if (!c->has_gpt) FAIL(c, "car_generate: this context holds VQ weights only");
@@ -379,7 +404,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         int skip = 0; { const char* ev = CAR_KNOB("CAR_DEBUG_SKIP_STEPS"); if (ev) { skip = atoi(ev); if (skip < 0 || skip > n_new - 2) skip = 0; } }
         c->dbg_skip = skip;
         for (int i = 0; i < 8; ++i) { c->h_init[2 * i] = T + skip; c->h_init[2 * i + 1] = skip; }    // (pos, step) per chain: after prefill the first decode step runs at input_pos = T, sampling token index 1
-        HIPCHK(c, hipMemcpyAsync(pos, c->h_init, 64, hipMemcpyHostToDevice, st));
+        car_launch_set_pos_step(pos, c->h_init[0], c->h_init[1], st);
     }
 
     // ---- D. text prefix embed: cls_embedding.cap_proj (gpt_t2i.py:435), uncond rows = uncond_embedding (generate.py:157)
@@ -506,7 +531,8 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             if (one_launch) gr.nsplit = 1;
             { const char* ev = CAR_KNOB("CAR_ATTN_NSPLIT"); if (ev) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) gr.nsplit = v; } }   // A/B knob: shorter attention workgroups
             // attention variant (decode2.hip; profiles/r02_kbench_*): 4 waves per (sequence, head) from 128 sequences up, 2 below; 16 in the one-launch small form
-            gr.attn_variant = (one_launch && gr.nsplit == 1) ? 160 : ((gr.nsplit == 1 && bg < 128) ? 20 : 40); gr.attn_lds_pad = 0;
+            // (round 6: the one-launch form is dec_attn2s_kernel, variant 162 — two blocks in flight per wave, bit-identical to 160; it needs T <= 512 and the jmin table)
+            gr.attn_variant = (one_launch && gr.nsplit == 1) ? ((T <= 512 && !CAR_KNOB("CAR_ATTN_OLD_SMALL")) ? 162 : 160) : ((gr.nsplit == 1 && bg < 128) ? 20 : 40); gr.attn_lds_pad = 0;
             { const char* ev = CAR_KNOB("CAR_ATTN_VARIANT"); if (ev) gr.attn_variant = atoi(ev); ev = CAR_KNOB("CAR_ATTN_LDS_PAD"); if (ev) gr.attn_lds_pad = atoi(ev); }
             // persistent attention grid: R resident workgroups per CU walk the (sequence, head) items in equal shares
             gr.attn_pgrid = 0;
@@ -607,7 +633,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
                  (const void*)forced_tokens, (void*)logits_out);
         { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
-                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0)));
+                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0) + (CAR_KNOB("CAR_NO_RUNAHEAD") ? 4 : 0)));
           strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         { const char* k1 = CAR_KNOB("CAR_ATTN_F32_FORM"); const char* k2 = CAR_KNOB("CAR_LINEAR_PRIO"); const char* k3 = CAR_KNOB("CAR_NORMX_MAX"); const char* k4 = CAR_KNOB("CAR_NORMX_J4"); char kb3[64]; snprintf(kb3, sizeof(kb3), "|x%s|%s|%s|%s", k1 ? k1 : "-", k2 ? k2 : "-", k3 ? k3 : "-", k4 ? k4 : "-"); strncat(keyb, kb3, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
@@ -640,13 +666,13 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
         if (graph_ok && nrem > 0) graph_ok = get_exec(gsteps > 1 ? c->gexec1 : c->gexec, gsteps > 1 ? c->gkey1 : c->gkey, 1);
         if (graph_ok && !step_rc) {
             for (int i = 0; i < n_early; ++i) HIPCHK(c, hipGraphLaunch(c->gexec1, st));
-            if (n_early > 0 && nmain > 0) HIPCHK(c, hipMemcpyAsync(pos, c->h_init2, 64, hipMemcpyHostToDevice, st));
+            if (n_early > 0 && nmain > 0) car_launch_set_pos_step(pos, c->h_init2[0], c->h_init2[1], st);
             for (int i = 0; i < nrep; ++i) HIPCHK(c, hipGraphLaunch(c->gexec, st));
             for (int i = 0; i < nrem; ++i) HIPCHK(c, hipGraphLaunch(gsteps > 1 ? c->gexec1 : c->gexec, st));
             c->stats.graph_used = 1;
         } else if (!step_rc) {
             early(true); for (int i = 0; i < n_early; ++i) enqueue_steps(1); early(false);
-            if (n_early > 0 && nmain > 0) HIPCHK(c, hipMemcpyAsync(pos, c->h_init2, 64, hipMemcpyHostToDevice, st));
+            if (n_early > 0 && nmain > 0) car_launch_set_pos_step(pos, c->h_init2[0], c->h_init2[1], st);
             for (int i = 0; i < nmain; ++i) enqueue_steps(1);
         }
     }

@@ -66,6 +66,7 @@ void car_launch_conv_out(int mode, const void* x, const void* w, const float* bi
 void car_launch_swiglu(int mode, const void* in, void* out, long rows, int hidden, hipStream_t st);
 void car_launch_sample_greedy(const SampleP* p, hipStream_t st);
 void car_launch_advance(int* pos, int* step, hipStream_t st);
+void car_launch_set_pos_step(int* dst, int pos, int step, hipStream_t st);
 void car_launch_transpose_pad(int mode, const void* src, long ld, long sb, void* dst, int B, int Tn, int Tpad, int C, hipStream_t st);
 void car_launch_gather_rows(int mode, const void* table, const int* idx, void* out, long rows, int D, hipStream_t st);
 void car_launch_label_index(const int64_t* labels, const int* row_img, const int* row_unc, int num_classes, int* idx, int* err_flag, int b, hipStream_t st);

@@ -976,6 +976,10 @@ extern "C" void car_launch_sample_greedy(const SampleP* p, hipStream_t st) {
 // step bookkeeping: pos += 1, step += 1 (device-side so a captured hipGraph can be replayed)
 __global__ void advance_kernel(int* pos, int* step) { if (threadIdx.x == 0) { *pos += 1; *step += 1; } }
 extern "C" void car_launch_advance(int* pos, int* step, hipStream_t st) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, pos, step); }
+// (pos, step) of all 8 chain slots from kernel ARGUMENTS (the copy from pageable context memory it replaces could block the host until the stream
+// drained and, under a caller's stream capture, read the host words at replay time)
+__global__ void set_pos_step_kernel(int* dst, int pos, int step) { if (threadIdx.x < 16) dst[threadIdx.x] = (threadIdx.x & 1) ? step : pos; }
+extern "C" void car_launch_set_pos_step(int* dst, int pos, int step, hipStream_t st) { hipLaunchKernelGGL(set_pos_step_kernel, dim3(1), dim3(64), 0, st, dst, pos, step); }
 
 // ------------------------------------------------------------------ V^T builder for the GEMM-form attention
 // src [B, Tn, ld] (column offset already applied), C channels -> dst [B, C, Tpad], zero padded in t.

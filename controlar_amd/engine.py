@@ -89,9 +89,19 @@ class Engine:
             raise RuntimeError(f"{what}: {self.lib.car_last_error(self._h).decode()}")
 
     def close(self):
+        """Destroys the context.  A device-side error that no entry could report synchronously (wrong first_valid hint, out-of-range device label) is raised here
+        at the latest — after the context is gone, so that close() always releases the memory."""
         if getattr(self, "_h", None):
-            self.lib.car_destroy(self._h)
-            self._h = None
+            h, self._h = self._h, None
+            rc, msg = 0, ""
+            try:
+                rc = self.lib.car_check_errors(h)
+                if rc:
+                    msg = (self.lib.car_last_error(h) or b"").decode(errors="replace")
+            finally:
+                self.lib.car_destroy(h)
+            if rc:
+                raise RuntimeError(f"car_check_errors at close(): {msg}")
 
     def __del__(self):
         try:
@@ -140,7 +150,10 @@ class Engine:
                  temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, sample_logits: bool = False, seed: int = 0,
                  forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False, first_valid: Optional[int] = None):
         """`first_valid`: a lower bound of the first valid (unpadded) prompt position over the batch, if the caller knows it — car_generate then sizes its prefill
-        window without reading the device mask back (no host wait).  A mask that is still on the host supplies it for free."""
+        window without reading the device mask back (no host wait).  A mask that is still on the host supplies it for free, and a caller-supplied value is
+        checked against such a mask here.  With a DEVICE mask a value that is too large cannot be seen without the host wait the hint exists to avoid: the
+        device raises a sticky error flag, and it surfaces at the NEXT entry into the context, at stats(), check_errors() or close() — the tokens of the
+        offending call are invalid."""
         c2i = self.cfg.gpt.model_type == "c2i"
         if c2i and cond.device.type == "cpu" and cond.numel():
             # labels that are still on the host are checked for free; device-resident labels are checked on the device (sticky flag, stats())
@@ -160,8 +173,12 @@ class Engine:
         mask_t = None
         if emb_masks is not None:
             assert emb_masks.shape[0] == B and emb_masks.shape[-1] == T          # generate.py:185-186
-            if first_valid is None and emb_masks.device.type == "cpu" and emb_masks.numel():
-                first_valid = first_valid_position(emb_masks.reshape(B, T))
+            if emb_masks.device.type == "cpu" and emb_masks.numel():
+                true_first = first_valid_position(emb_masks.reshape(B, T))
+                if first_valid is not None and int(first_valid) > true_first:
+                    raise RuntimeError(f"generate: first_valid={int(first_valid)} is beyond the first valid prompt position of the batch ({true_first}): valid rows would be dropped")
+                if first_valid is None:
+                    first_valid = true_first
             mask_t = emb_masks.to(device=self.device, dtype=torch.int64).contiguous()
         sp = L.CarSampling()
         sp.first_valid_hint = 0 if (first_valid is None or emb_masks is None) else max(0, min(int(first_valid), T)) + 1
@@ -269,6 +286,7 @@ class Engine:
     def stats(self) -> dict:
         s = L.CarStats()
         self._check(self.lib.car_get_stats(self._h, C.byref(s)), "car_get_stats")
+        self._check(self.lib.car_check_errors(self._h), "car_check_errors")          # car_get_stats waited for the stream: a sticky device error is visible now
         return dict(decode_ms=s.decode_ms, prefill_ms=s.prefill_ms, decode_steps=s.decode_steps,
                     decode_algo_bytes=s.decode_algo_bytes, decode_kernels_per_step=s.decode_kernels_per_step,
                     graph_used=bool(s.graph_used), dev_knobs_active=int(s.dev_knobs_active))

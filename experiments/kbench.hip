@@ -175,7 +175,8 @@ static void test_qkv_attn(const AttnCase& c) {
     Attn2P a; memset(&a, 0, sizeof(a)); a.q = dQ; a.kc = dK; a.vc = dV; a.pos = dPos; a.mask = c.maskmode ? dM : nullptr; a.out = dO; a.part = dPart;
     a.H = H; a.SA = SA; a.T = T; a.dim = dim; a.nsplit = c.nsplit; a.out_packed = c.packed_out;
     int* dJ = dalloc<int>(b);
-    if (c.maskmode && (c.variant % 2 == 0 || c.variant == 41)) { car_launch_mask_first_valid(dM, dJ, b, T, 0); a.jmin = dJ; }     // both jmin sources get exercised
+    if (c.maskmode && (c.variant % 2 == 0 || c.variant == 41)) { car_launch_mask_first_valid(dM, dJ, b, T, 0); a.jmin = dJ; }
+    if (c.variant == 162 && (b * H) % 8 == 0) { a.pf_wgs = 24; a.pf_p0 = dW; a.pf_b0 = (unsigned)(wp.size() * 2); }      // run-ahead helpers ride along (they only read)     // both jmin sources get exercised
     car_launch_dec_attn2_var(&a, b, c.variant, 0, 0);
     CK(hipDeviceSynchronize());
     // cache rows written by the epilogue
@@ -258,6 +259,66 @@ static void test_gemm_norm() {
         char nm[96]; snprintf(nm, sizeof(nm), "dec_gemm fused-norm cfg %d add=%d vs rmsnorm2 + dec_gemm (bit-exact)", cfg, add); report(nm, e + eh, 0.0);
     }
     for (void* q : {(void*)dH, (void*)dWn, (void*)dC, (void*)dW, (void*)dX, (void*)dH1, (void*)dH2, (void*)dO1, (void*)dO2, (void*)dPos}) CK(hipFree(q));
+}
+
+
+// ------------------------------------------------------------------------------------------------ round 6: normalise-on-the-fly GEMM, 16-wave tiles, small-batch attention
+static void test_gemm_normx() {
+    for (int M : {2, 5, 16}) {
+        const int D = 1280, N = 512, NP = D / 16;
+        std::vector<bf16_t> h((size_t)M * D), w(D); for (auto& v : h) v = f2bf(frand() * 3.f); for (auto& v : w) v = f2bf(1.f + 0.1f * frand());
+        std::vector<float> W((size_t)N * D); for (auto& v : W) v = rb(frand() * 0.1f);
+        std::vector<float> ssq((size_t)M * NP);
+        for (int m = 0; m < M; ++m) for (int pr = 0; pr < NP; ++pr) { float a = 0.f; for (int k = 0; k < 16; ++k) { const float x = bf2f(h[(size_t)m * D + pr * 16 + k]); a += x * x; } ssq[(size_t)m * NP + pr] = a; }
+        // the kernel's fold: lane q4 adds the four floats of chunks q4, q4 + 4, ... in order, then (s0 + s1) + (s2 + s3)
+        std::vector<double> ref((size_t)M * N);
+        for (int m = 0; m < M; ++m) {
+            float sq[4] = {0, 0, 0, 0};
+            for (int q = 0; q < 4; ++q) for (int ci = q; ci < NP / 4; ci += 4) for (int e = 0; e < 4; ++e) sq[q] += ssq[(size_t)m * NP + ci * 4 + e];
+            const float tot = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+            const float rstd = 1.0f / sqrtf(tot / D + 1e-5f);
+            std::vector<float> x(D); for (int k = 0; k < D; ++k) x[k] = rb(rb(bf2f(h[(size_t)m * D + k]) * rstd) * bf2f(w[k]));
+            for (int n = 0; n < N; ++n) { double a = 0; for (int k = 0; k < D; ++k) a += (double)x[k] * W[(size_t)n * D + k]; ref[(size_t)m * N + n] = a; }
+        }
+        auto wp = pack_rows(W, N, D);
+        bf16_t* dH = dalloc<bf16_t>(h.size()); h2d(dH, h); bf16_t* dWn = dalloc<bf16_t>(D); h2d(dWn, w); bf16_t* dW = dalloc<bf16_t>(wp.size()); h2d(dW, wp);
+        float* dS = dalloc<float>(ssq.size()); h2d(dS, ssq); float* dO = dalloc<float>((size_t)M * N);
+        for (int cfg : {111, 110, 211, 411, 120}) {
+            CK(hipMemset(dO, 0xff, (size_t)M * N * 4));
+            GemmDP q; memset(&q, 0, sizeof(q)); q.W = dW; q.M = M; q.N = N; q.K = D; q.outf = dO; q.nh_in = dH; q.nw = dWn; q.neps = 1e-5f; q.ssq_in = dS; q.ssq_np = NP; q.w_nt = 1;
+            if (car_launch_dec_gemm_cfg(&q, EPI_LOGITS, cfg, 0)) { printf("normx cfg %d rejected\n", cfg); ++g_fail; continue; }
+            CK(hipDeviceSynchronize());
+            auto o = d2h(dO, (size_t)M * N);
+            double e = 0; for (size_t i = 0; i < o.size(); ++i) e = std::max(e, std::fabs((double)o[i] - (double)rb((float)ref[i])));
+            char nm[96]; snprintf(nm, sizeof(nm), "dec_gemm NORM==2 (on-the-fly RMSNorm) cfg %d M=%d K=%d", cfg, M, D); report(nm, e, 0.3);      // |x| up to ~40: one bf16 ulp = 0.25
+        }
+        for (void* q : {(void*)dH, (void*)dWn, (void*)dW, (void*)dS, (void*)dO}) CK(hipFree(q));
+    }
+}
+static void test_gemm_w16() {      // cfg 112 (16 waves) against cfg 111: RESID with the sum-of-squares partials, with and without run-ahead helper workgroups — bit for bit
+    for (int K : {1280, 3584}) {
+        const int M = 7, N = 256;
+        std::vector<float> X((size_t)M * K), W((size_t)N * K); for (auto& v : X) v = rb(frand()); for (auto& v : W) v = rb(frand() * 0.05f);
+        auto xp = pack_rows(X, M, K), wp = pack_rows(W, N, K);
+        std::vector<bf16_t> h0((size_t)M * N); for (auto& v : h0) v = f2bf(frand() * 2.f);
+        bf16_t* dX = dalloc<bf16_t>(xp.size()); h2d(dX, xp); bf16_t* dW = dalloc<bf16_t>(wp.size()); h2d(dW, wp);
+        bf16_t* dH1 = dalloc<bf16_t>(h0.size()); bf16_t* dH2 = dalloc<bf16_t>(h0.size()); float* dS1 = dalloc<float>((size_t)M * N / 16); float* dS2 = dalloc<float>((size_t)M * N / 16);
+        unsigned* junk = dalloc<unsigned>((size_t)(8 << 20) / 4); CK(hipMemset(junk, 1, 8 << 20));
+        for (int pf : {0, 64}) {
+            h2d(dH1, h0); h2d(dH2, h0);
+            GemmDP p; memset(&p, 0, sizeof(p)); p.W = dW; p.X = dX; p.M = M; p.N = N; p.K = K; p.w_nt = 1; p.ssq_ld = N / 16;
+            p.h = dH1; p.ssq_out = dS1; car_launch_dec_gemm_cfg(&p, EPI_RESID, 111, 0);
+            p.h = dH2; p.ssq_out = dS2; p.pf_wgs = pf; p.pf_p0 = junk; p.pf_b0 = 8u << 20; p.pf_p1 = (const char*)junk + 12345 * 128; p.pf_b1 = 3u << 20;
+            if (car_launch_dec_gemm_cfg(&p, EPI_RESID, 112, 0)) { printf("cfg 112 rejected\n"); ++g_fail; }
+            CK(hipDeviceSynchronize());
+            auto a = d2h(dH1, h0.size()), b2 = d2h(dH2, h0.size()); auto s1 = d2h(dS1, (size_t)M * N / 16), s2 = d2h(dS2, (size_t)M * N / 16);
+            double e = 0, es = 0; for (size_t i = 0; i < a.size(); ++i) e = std::max(e, std::fabs((double)bf2f(a[i]) - bf2f(b2[i])));
+            for (size_t i = 0; i < s1.size(); ++i) es = std::max(es, std::fabs((double)s1[i] - s2[i]) / std::max(1.0, (double)std::fabs(s1[i])));
+            char nm[128]; snprintf(nm, sizeof(nm), "dec_gemm RESID cfg 112 (16 waves, %d helper workgroups) vs cfg 111, K=%d: h", pf, K); report(nm, e, 0.07);
+            snprintf(nm, sizeof(nm), "   ... sum-of-squares partials (relative)"); report(nm, es, 2e-2);
+        }
+        for (void* q : {(void*)dX, (void*)dW, (void*)dH1, (void*)dH2, (void*)dS1, (void*)dS2, (void*)junk}) CK(hipFree(q));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ timing
@@ -370,11 +431,16 @@ int main(int argc, char** argv) {
     test_gemm();
     test_norm();
     test_gemm_norm();
+    test_gemm_normx();
+    test_gemm_w16();
     const AttnCase cases[] = {
         {3, 2, 40, 40, 1, 0, 1, 0}, {3, 2, 40, 63, 1, 1, 1, 0}, {3, 2, 40, 64, 1, 1, 1, 0}, {3, 2, 40, 250, 1, 1, 1, 0}, {3, 2, 40, 250, 4, 1, 1, 0}, {20, 2, 40, 131, 2, 0, 1, 0},
         {3, 2, 40, 97, 1, 1, 2, 0}, {3, 2, 40, 97, 4, 1, 2, 0}, {2, 1, 1, 1, 1, 1, 0, 0}, {2, 1, 1, 33, 16, 1, 0, 0}, {17, 3, 120, 600, 1, 1, 1, 0}, {5, 2, 120, 1143, 1, 1, 1, 0},
     };
     for (int variant : {41, 40, 21, 20}) for (auto c : cases) { c.variant = variant; test_qkv_attn(c); }
+    // one-launch 16-wave forms (small batch): the round-3 kernel and round 6's two-blocks-in-flight kernel, nsplit 1 only, incl. a 1656-position (MR) cache
+    for (int variant : {160, 162}) for (auto c : cases) { if (c.nsplit != 1) continue; c.variant = variant; test_qkv_attn(c); }
+    for (int variant : {160, 162}) { AttnCase c = {2, 2, 120, 1650, 1, 1, 1, variant}; test_qkv_attn(c); AttnCase c2 = {8, 4, 120, 1023, 1, 1, 1, variant}; test_qkv_attn(c2); }
     printf("== correctness: %d failure(s)\n", g_fail);
     fflush(stdout);
     const bool only_gemm = argc > 1 && !strcmp(argv[1], "gemm");

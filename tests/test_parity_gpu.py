@@ -213,7 +213,15 @@ def test_first_valid_hint_replaces_the_host_wait_and_is_checked_on_the_device():
         eng.generate(emb.cuda(), 16, mask.cuda(), cfg_scale=1.0)
     got = eng.generate(emb.cuda(), 16, mask.cuda(), cfg_scale=1.0).cpu()                        # the flag is cleared by the call that reported it
     assert torch.equal(got, want)
-    eng.close()
+    # a wrong hint must not go unnoticed by a caller that makes ONE call — a host mask is checked before anything is enqueued, stats() and close() report the flag
+    with pytest.raises(RuntimeError, match="first_valid"):
+        eng.generate(emb.cuda(), 16, mask, cfg_scale=1.0, first_valid=T - 12)
+    eng.generate(emb.cuda(), 16, mask.cuda(), cfg_scale=1.0, first_valid=T - 12)
+    with pytest.raises(RuntimeError, match="first_valid_hint"):
+        eng.stats()
+    eng.generate(emb.cuda(), 16, mask.cuda(), cfg_scale=1.0, first_valid=T - 12)
+    with pytest.raises(RuntimeError, match="first_valid_hint"):
+        eng.close()
 
 
 def test_error_paths_raise():
@@ -611,4 +619,32 @@ def test_chain_schedule_knobs_do_not_change_tokens(chains, monkeypatch):
         assert torch.equal(got, want), env
         again = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=1.0).cpu()      # replay of the cached graphs
         assert torch.equal(again, want), env
+    eng.close()
+
+
+@pytest.mark.parametrize("B,cfg_scale", [(1, 4.0), (8, 1.0), (3, 1.0)])
+def test_small_chain_runahead_and_attention_do_not_change_a_bit(B, cfg_scale, monkeypatch):
+    """Round 6, chains of one m-block (BASELINE configs 2, 4, 5): the L2 run-ahead helper workgroups only READ weights, and the two-blocks-in-flight attention
+    (dec_attn2s_kernel) keeps dec_attn2_kernel<16>'s block -> wave assignment and merge order — tokens AND logits must equal the round-5 schedule's bit for bit
+    (B = 3 is a grid that is not a multiple of 8: the helpers switch themselves off there)."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    cfg = C.tiny_t2i(64, "canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    H, W, n_new = 128, 128, 40
+    img = synth.canny_like_control(B, H, W)
+    emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    eng = Engine(cfg, "bf16", dev=True); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    monkeypatch.setenv("CAR_NO_RUNAHEAD", "1"); monkeypatch.setenv("CAR_ATTN_OLD_SMALL", "1")
+    want, want_l = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=cfg_scale, return_logits=True)
+    want, want_l = want.cpu(), want_l.cpu()
+    for env in ({"CAR_ATTN_OLD_SMALL": "1"}, {"CAR_NO_RUNAHEAD": "1"}, {}):
+        monkeypatch.delenv("CAR_NO_RUNAHEAD", raising=False); monkeypatch.delenv("CAR_ATTN_OLD_SMALL", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, got_l = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=cfg_scale, return_logits=True)
+        assert eng.stats()["graph_used"], env
+        assert torch.equal(got.cpu(), want), env
+        assert torch.equal(got_l.cpu(), want_l), env
     eng.close()
