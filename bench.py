@@ -72,7 +72,7 @@ def parse():
                     help="run the VQ decode of batch i on a side stream under the token loop of batch i+1 (measured: no gain on MI355X — "
                          "the token loop is HBM-bound and the decoder's GEMM grids take every CU; kept for experiments)")
     ap.add_argument("--cpu-tokens", type=int, default=48, help="decode tokens timed by the CPU baseline sample")
-    ap.add_argument("--exact-leg-steps", type=int, default=2,
+    ap.add_argument("--exact-leg-steps", type=int, default=3,
                     help="headline configuration on one GPU only: after the timed region, time this many steps (+ 1 warm-up) of the BIT-IDENTICAL mode (`--precision fp32`, 384 "
                          "images) in a child process and report it as the `exact` block of the same JSON line — north_star asks for >= 20 images/s WITH the reference's greedy "
                          "tokens; the bf16 headline is tolerance-graded, this leg is the one whose tokens are compared with the reference's.  0 = skip")

@@ -47,6 +47,19 @@ template <> struct ET<bf16_t> {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 
+// A decode kernel's parameter block is 150-300 bytes = 3-5 cache lines of the kernarg segment.  hipcc places each s_load next to its first use with an
+// s_waitcnt in front of the next, so a cold kernel start walked the lines one scalar-cache miss after the other (five dependent misses in dec_gemm's prologue:
+// ISA of round 5).  Touch every line up front — independent s_loads, one wait — and the later field loads hit the scalar cache.
+template <int NLINES>
+__device__ __forceinline__ void car_kernarg_prefetch() {
+    const __attribute__((address_space(4))) unsigned* ka = (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t[NLINES];
+#pragma unroll
+    for (int i = 0; i < NLINES; ++i) t[i] = ka[i * 16];
+#pragma unroll
+    for (int i = 0; i < NLINES; ++i) asm volatile("" ::"s"(t[i]));
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

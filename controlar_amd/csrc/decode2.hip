@@ -51,19 +51,6 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {          // v_cvt_pk_
 #define STAMP(p, i) do { } while (0)
 #endif
 
-// A decode kernel's parameter block is 150-300 bytes = 3-5 cache lines of the kernarg segment.  hipcc places each s_load next to its first use with an
-// s_waitcnt in front of the next, so a cold kernel start walked the lines one scalar-cache miss after the other (five dependent misses in dec_gemm's prologue:
-// ISA of round 5).  Touch every line up front — independent s_loads, one wait — and the later field loads hit the scalar cache.
-template <int NLINES>
-__device__ __forceinline__ void car_kernarg_prefetch() {
-    const __attribute__((address_space(4))) unsigned* ka = (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned t[NLINES];
-#pragma unroll
-    for (int i = 0; i < NLINES; ++i) t[i] = ka[i * 16];
-#pragma unroll
-    for (int i = 0; i < NLINES; ++i) asm volatile("" ::"s"(t[i]));
-}
-
 // L2 run-ahead helper (decode2_params.h CAR_PF_FIELDS): workgroup `hidx` of `pf_wgs` helpers touches one dword per 128-byte line of its XCD's eighth of up to two
 // tensors, U lines per lane in flight.  Plain loads (default cache policy: the consumers' non-temporal loads hit the lines); nothing is stored.
 __device__ inline void car_pf_helper(const void* p0, unsigned b0, const void* p1, unsigned b1, int hidx, int pf_wgs) {
@@ -102,6 +89,8 @@ __device__ inline void car_pf_helper(const void* p0, unsigned b0, const void* p1
 #define HS_ARRIVE(p) do { } while (0)
 #endif
 typedef unsigned long long u64_t;
+typedef __attribute__((address_space(1))) const void car_gptr_t;
+typedef __attribute__((address_space(3))) void car_lptr_t;
 __device__ __forceinline__ u64_t car_ld8_agent(const void* q) { return __hip_atomic_load((const u64_t*)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // 16 bytes the predecessor kernel wrote (fresh != 0: two 8-byte agent-scope loads) or anything older (a plain 16-byte load)
 __device__ __forceinline__ u32x4 car_ld16(const void* q, bool fresh) {
@@ -191,10 +180,10 @@ __device__ inline long bf16x8_to_fp8x8_(const u32x4 x) {
 template <int I, int J, int WAVES, int EPI, int F8, int NORM>
 __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     extern __shared__ __attribute__((aligned(16))) float red_all[];   // [NORM: 16 x (K+8) bf16] then [WAVES][I*J][64] f32x4
-    static_assert(NORM != 1 || J == 1, "the prologue-norm variant serves one m-block");
+    static_assert((NORM != 1 && NORM != 3) || J == 1, "the prologue-norm and staged-norm variants serve one m-block");
     const int xs_ld = p.K + 8;                                         // bf16 elements per LDS row: 16-byte reads of 16 rows hit 16 distinct bank groups
     bf16_t* xs = (bf16_t*)red_all;
-    float* red = NORM == 1 ? red_all + (16 * xs_ld) / 2 : red_all;
+    float* red = NORM == 1 ? red_all + (16 * xs_ld) / 2 : (NORM == 3 ? red_all + ((size_t)WAVES * p.stg) / 4 : red_all);
     constexpr int XPU = F8 ? 2 : 1;                                    // X chunks (k-blocks) per weight load unit
     car_kernarg_prefetch<(sizeof(GemmDP) + 63 + 48) / 64>();           // the block + the hidden grid-size arguments behind it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -214,7 +203,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     // the M tiles that share a weight row-block then hit the same L2
     int t = blockIdx.x; const int total = (int)gridDim.x - p.pf_wgs;
     if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
-    const int nt = t / MT, mt = t - nt * MT;
+    const int nt = (NORM == 3) ? t : t / MT, mt = t - nt * MT;         // (NORM == 3: one m-block, MT == 1 — no division in the latency-bound prologue)
     const int rb0 = nt * I, mb0 = mt * J;
     const int jn = (Mb - mb0) < J ? (Mb - mb0) : J;                    // m-blocks that exist in this tile (wave-uniform)
     const int ku_lo = (int)((long)nku * wave / WAVES), ku_hi = (int)((long)nku * (wave + 1) / WAVES);
@@ -257,20 +246,41 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (j < jn) x[j * XPU + u] = car_ld16(xp + ((long)j * nkb + ku * XPU + u) * 64, hs_fresh); }
+                for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (j < jn) x[j * XPU + u] = car_ld16(xp + ((long)j * nkb + ku * XPU + u) * 64, hs_fresh); }      // (round 6 tried masking the lanes of rows >= M: the exec juggling cost more issue time than the narrower loads saved — wo 0.52 -> 0.86 us, w2 1.16 -> 1.42)
         } else if (NORM == 2) {
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int u = 0; u < XPU; ++u) x[j * XPU + u] = car_ld16(hrow[j] + (ku * XPU + u) * 32, hs_fresh);      // unconditional (rows >= M read row 0 and meet rstd = 0): a predicated load costs a branch and the compiler's vmcnt accounting
+                for (int u = 0; u < XPU; ++u) { x[j * XPU + u] = zw; if (hok[j]) x[j * XPU + u] = car_ld16(hrow[j] + (ku * XPU + u) * 32, hs_fresh); }
         }
     };
     auto load = [&](u32x4 (&w)[I], u32x4 (&x)[J * XPU], u32x4 (&nwf)[NORM == 2 ? XPU : 1], int ku) { loadW(w, nwf, ku); loadX(x, ku); };
     const bf16_t* xl = xs + (lane & 15) * xs_ld + (lane >> 4) * 8;     // NORM == 1: this lane's row / k offset inside a k-block
+    // NORM == 3: the wave-private staging region [X rounds][norm weight: 1 KiB][partials rounds], 1 KiB per DMA instruction
+    const int s_nkbw = NORM == 3 ? (ku_hi - ku_lo) * XPU : 0;           // k-blocks of this wave's slice
+    const int s_xr = NORM == 3 ? (p.M * ((nku + WAVES - 1) / WAVES) * XPU * 4 + 63) >> 6 : 0;
+    const int s_row = (lane & 15) < p.M ? (lane & 15) : p.M - 1;
+    const char* stg_x = (const char*)red_all + (size_t)wave * (NORM == 3 ? p.stg : 0);
+    const char* stg_w = stg_x + (size_t)s_xr * 1024;
+    const char* stg_s = stg_w + 1024;
     auto compute = [&](const u32x4 (&w)[I], u32x4 (&x)[J * XPU], const u32x4 (&nwf)[NORM == 2 ? XPU : 1], int ku) {
         if (NORM == 1) {
 #pragma unroll
             for (int u = 0; u < XPU; ++u) x[u] = *(const u32x4*)(xl + (ku * XPU + u) * 32);
+        } else if (NORM == 3) {
+            // staged operands: this lane's 16 bytes of row min(c16, M-1) and of the norm weight for k-block (ku * XPU + u), then the arithmetic of NORM == 2
+#pragma unroll
+            for (int u = 0; u < XPU; ++u) {
+                const int kq = ((ku - ku_lo) * XPU + u) * 4 + (lane >> 4);
+                x[u] = *(const u32x4*)(stg_x + ((size_t)s_row * (s_nkbw * 4) + kq) * 16);
+                const u32x4 wq = *(const u32x4*)(stg_w + (size_t)kq * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned hv = x[u][e], wv = wq[e];
+                    const unsigned t = pack_bf16x2(__uint_as_float(hv << 16) * rstd[0], __uint_as_float(hv & 0xffff0000u) * rstd[0]);
+                    x[u][e] = pack_bf16x2(__uint_as_float(t << 16) * __uint_as_float(wv << 16), __uint_as_float(t & 0xffff0000u) * __uint_as_float(wv & 0xffff0000u));
+                }
+            }
         } else if (NORM == 2) {
             // x = rnd(rnd(h * rstd) * w) — the rounding points of rmsnorm2_kernel (gpt_t2i.py:193-198), two bf16 per dword
 #pragma unroll
@@ -340,21 +350,16 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     float4 sv[(NORM == 2 && J <= 2) ? J : 1][8];
     auto ssq_issue = [&](float4 (&v)[8], int j) {
         const int np4 = p.ssq_np >> 2, q4n = lane >> 4;
-        // unconditional loads at clamped addresses, the out-of-range ones zeroed by a select afterwards (adding +0 leaves the fixed-order sum's bits alone).  Round 5's
-        // predicated form compiled to a branch per load and an s_waitcnt vmcnt(0) behind each of the first two: two serialised round trips in front of the weight stream.
-        const float4* sp = (const float4*)(p.ssq_in + (long)(hok[j] ? (mb0 + j) * 16 + (lane & 15) : 0) * p.ssq_np);
+        // (round 6 tried unconditional loads at clamped addresses + selects here: fewer branches, but ~45 % more prologue instructions — at 24-64 rows, where 15 waves
+        //  per CU run this prologue at once, the layer lost 6-32 us (profiles/r06_lat_probe_mid_rows_regression.txt).  One m-block chains use NORM == 3 instead.)
+        const float4* sp = (const float4*)(p.ssq_in + (long)((mb0 + j) * 16 + (lane & 15)) * p.ssq_np);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int ci = q4n + 4 * t;
-            if (4 * t < np4) { const u32x4 r = car_ld16(sp + (ci < np4 ? ci : np4 - 1), hs_fresh); v[t] = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])); }      // (wave-uniform bound)
-            else v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int t = 0; t < 8; ++t) { v[t] = make_float4(0.f, 0.f, 0.f, 0.f); if (hok[j] && q4n + 4 * t < np4) { const u32x4 r = car_ld16(sp + q4n + 4 * t, hs_fresh); v[t] = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])); } }
     };
     auto ssq_finish = [&](const float4 (&v)[8], int j) {
         float sum = 0.f;
-        const int np4 = p.ssq_np >> 2, q4n = lane >> 4;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const bool ok = hok[j] && q4n + 4 * t < np4; sum += ok ? v[t].x : 0.f; sum += ok ? v[t].y : 0.f; sum += ok ? v[t].z : 0.f; sum += ok ? v[t].w : 0.f; }
+        for (int t = 0; t < 8; ++t) { sum += v[t].x; sum += v[t].y; sum += v[t].z; sum += v[t].w; }
         sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
         rstd[j] = hok[j] ? rsqrtf(sum / p.K + p.neps) : 0.f;
     };
@@ -363,10 +368,13 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     // trips (pos -> rope row, or the residual load) after the fold.  Unconditional loads at clamped addresses; later units (u > wave) load in the loop as before.
     // (Early launch: the residual stream was last written two kernels back — complete before this kernel was dispatched.)
     constexpr int IPc = I >= 2 ? I / 2 : 1, IWc = I >= 2 ? 2 : 1;
-    const bool epi_first = wave < IPc * J;                               // wave-uniform
+    const bool epi_first = wave < IPc * J && p.M <= 16;                  // wave-uniform; one m-block chains only (the latency-bound regime: elsewhere the extra prologue instructions cost more than the round trip)
     uint2 hv_h[IWc]; float4 cs_h[IWc];
     int pos_h = 0;
-    if (EPI == EPI_QKV) pos_h = *(const __attribute__((address_space(4))) int*)(unsigned long long)p.pos;      // constant for the kernel's lifetime: read through the scalar cache (an s_load whose wait the compiler places at the first use)
+    // *pos is read up front only in one-m-block chains (a single-branch graph: every kernel completes before the next starts).  With two chains as parallel graph
+    // branches an EARLY read — even an agent-scope one served by L2 — returned the previous step's position in some workgroups (tools/twin_probe.py: twin rows in
+    // different chains diverged after 6-50 steps), while the read in the epilogue, a few microseconds later, never has: the large-batch kernels keep round 5's late read.
+    if (EPI == EPI_QKV && p.M <= 16) pos_h = *(const __attribute__((address_space(4))) int*)(unsigned long long)p.pos;      // constant for the kernel's lifetime: through the scalar cache
     if (EPI == EPI_RESID && epi_first) {
         const int ip0 = wave / J, j0 = wave - ip0 * J;
         int m0 = (mb0 + j0) * 16 + (lane & 15); m0 = m0 < p.M ? m0 : p.M - 1;
@@ -410,6 +418,21 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) if (d < nkw) loadX(xr[d], ku_lo + d);
     } else {
+        if (NORM == 3 && s_nkbw > 0) {      // lane-dense DMA of this wave's X slice, norm-weight slice and the rows' partials (clamped chunk indices: every lane loads something valid)
+            const int c4 = s_nkbw * 4, xtot = p.M * c4, kb0 = ku_lo * XPU;
+            for (int r = 0; r < s_xr; ++r) {                            // wave-uniform trip count
+                int ci = lane + 64 * r; ci = ci < xtot ? ci : xtot - 1;
+                const int m = ci / c4, k8 = ci - m * c4;
+                __builtin_amdgcn_global_load_lds((car_gptr_t*)(p.nh_in + (long)m * p.K + kb0 * 32 + k8 * 8), (car_lptr_t*)(stg_x + (size_t)r * 1024), 16, 0, 0);
+            }
+            { const int ci = lane < c4 ? lane : c4 - 1;
+              __builtin_amdgcn_global_load_lds((car_gptr_t*)(p.nw + kb0 * 32 + ci * 8), (car_lptr_t*)stg_w, 16, 0, 0); }
+            const int stot = p.M * (p.ssq_np >> 2), sr = (stot + 63) >> 6;
+            for (int r = 0; r < sr; ++r) {
+                int ci = lane + 64 * r; ci = ci < stot ? ci : stot - 1;
+                __builtin_amdgcn_global_load_lds((car_gptr_t*)(p.ssq_in + (long)ci * 4), (car_lptr_t*)(stg_s + (size_t)r * 1024), 16, 0, 0);
+            }
+        }
         if (NORM == 2) {
 #pragma unroll
             for (int j = 0; j < J; ++j) { if (J <= 2) ssq_issue(sv[j], j); else { ssq_issue(sv[0], j); ssq_finish(sv[0], j); } }
@@ -417,6 +440,22 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) if (d < nkw) load(wr[d], xr[d], nr[d], ku_lo + d);
         rope_first();
+    }
+    STAMP(p, 6);                                                       // every load of the prologue has been issued
+    if (NORM == 3) {
+        // the DMA is invisible to the compiler's wait-count pass: the covering vmcnt is ours (MI355X_MICROARCH.md: nothing orders a ds_read behind a pending LDS-DMA
+        // but the issuing wave's vmcnt).  rstd from the staged partials in the order of NORM == 2: lane q4 adds chunks q4, q4 + 4, ..., then (s0 + s1) + (s2 + s3).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int np4 = p.ssq_np >> 2, q4n = lane >> 4;
+        float sum = 0.f;
+        for (int t = 0; 4 * t < np4; ++t) {
+            const int ci = q4n + 4 * t;
+            const float4 v = *(const float4*)(stg_s + ((size_t)s_row * np4 + (ci < np4 ? ci : np4 - 1)) * 16);
+            const bool ok = ci < np4;
+            sum += ok ? v.x : 0.f; sum += ok ? v.y : 0.f; sum += ok ? v.z : 0.f; sum += ok ? v.w : 0.f;
+        }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        rstd[0] = (lane & 15) < p.M ? rsqrtf(sum / p.K + p.neps) : 0.f;
     }
     if (NORM == 2 && J <= 2) {
 #pragma unroll
@@ -505,7 +544,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     constexpr int IP = I >= 2 ? I / 2 : 1, IW = I >= 2 ? 2 : 1;
     const int q4 = lane >> 4, c16 = lane & 15;
     for (int u = wave; u < IP * J; u += WAVES) {
-        const bool first_u = u == wave;                                  // this unit's residual / RoPE operands were requested in the prologue
+        const bool first_u = u == wave && epi_first;                     // this unit's residual / RoPE operands were requested in the prologue
         const int ip = u / J, j = u - ip * J;
         if (j >= jn) continue;
         const int m = (mb0 + j) * 16 + c16;
@@ -555,7 +594,7 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
                         ssq_acc += s0 * s0; ssq_acc += s1 * s1; ssq_acc += s2 * s2; ssq_acc += s3 * s3;
                     }
                 } else {   // EPI_QKV
-                    const int pos = pos_h;
+                    const int pos = p.M <= 16 ? pos_h : *p.pos;
                     const int sec = n0 / p.dim, within = n0 - sec * p.dim, hh = within >> 6, d0 = within & 63;
                     const float x0 = bf2f(f2bf(a[0])), x1 = bf2f(f2bf(a[1])), x2 = bf2f(f2bf(a[2])), x3 = bf2f(f2bf(a[3]));   // Linear output -> bf16
                     const long sb = ((long)m * p.H + hh) * p.SA * 64;
@@ -605,10 +644,15 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
 }
 
 template <int I, int J, int WAVES, int F8, int NORM>
-static void launch_gemm_ij(const GemmDP& p, int epi, hipStream_t st) {
+static void launch_gemm_ij(const GemmDP& p_, int epi, hipStream_t st) {
+    GemmDP p = p_;
     const int Mb = (p.M + 15) / 16, MT = (Mb + J - 1) / J, NT = p.N / (16 * I);
     const dim3 g(NT * MT + (p.pf_wgs > 0 ? p.pf_wgs : 0)), b(WAVES * 64);
-    const size_t sh = (size_t)WAVES * I * J * 64 * 16 + (NORM == 1 ? (size_t)16 * (p.K + 8) * 2 : 0);
+    if (NORM == 3) {      // per-wave staging: X rounds + 1 (norm weight) + partials rounds, 1 KiB each
+        const int nku = p.K / (F8 ? 64 : 32), xr = (p.M * ((nku + WAVES - 1) / WAVES) * (F8 ? 2 : 1) * 4 + 63) / 64, sr = (p.M * (p.ssq_np / 4) + 63) / 64;
+        p.stg = (xr + 1 + sr) * 1024;
+    }
+    const size_t sh = (size_t)WAVES * I * J * 64 * 16 + (NORM == 1 ? (size_t)16 * (p.K + 8) * 2 : 0) + (NORM == 3 ? (size_t)WAVES * p.stg : 0);
     static size_t attr[4] = {0, 0, 0, 0};
 #define LG(E)                                                                                                                   \
     do {                                                                                                                        \
@@ -631,6 +675,19 @@ extern "C" int car_launch_dec_gemm_cfg(const GemmDP* p, int epi, int cfg, hipStr
     const int f8 = p->wscale ? (p->f8_mfma ? 2 : 1) : 0;
     if (p->ssq_in) {                                     // normalise-on-the-fly variant (NORM == 2): any tile; X = the bf16 residual rows themselves
         if (!p->nw || !p->nh_in || epi == EPI_RESID || p->ssq_np <= 0 || (p->ssq_np & 3) || p->ssq_np > 128) return -1;
+        // one m-block, 8-wave tiles: the staged form (NORM == 3) — same arithmetic, lane-dense operand loads.  Limits: a slice of at most 16 k-blocks per wave
+        // (one DMA instruction for the norm weight) and at least one k-unit for every wave.
+        {
+            const int nku = p->K / (f8 ? 64 : 32), nkw_max = (nku + 7) / 8;
+            if (p->M <= 16 && (cfg / 10) % 10 == 1 && cfg % 10 == 1 && nku >= 8 && nkw_max * (f8 ? 2 : 1) <= 16 && !CAR_KNOB("CAR_NO_STAGED_NORMX")) {
+                switch (cfg / 100) {
+#define CASE3(I) case I: if (f8 == 2) launch_gemm_ij<I, 1, 8, 2, 3>(*p, epi, st); else if (f8) launch_gemm_ij<I, 1, 8, 1, 3>(*p, epi, st); else launch_gemm_ij<I, 1, 8, 0, 3>(*p, epi, st); return 0;
+                    CASE3(1) CASE3(2) CASE3(4)
+#undef CASE3
+                    default: break;
+                }
+            }
+        }
         switch (cfg) {
 #define CASE(I, J) case I * 100 + J * 10: if (f8 == 2) launch_gemm_ij<I, J, 4, 2, 2>(*p, epi, st); else if (f8) launch_gemm_ij<I, J, 4, 1, 2>(*p, epi, st); else launch_gemm_ij<I, J, 4, 0, 2>(*p, epi, st); break; \
                    case I * 100 + J * 10 + 1: if (f8 == 2) launch_gemm_ij<I, J, 8, 2, 2>(*p, epi, st); else if (f8) launch_gemm_ij<I, J, 8, 1, 2>(*p, epi, st); else launch_gemm_ij<I, J, 8, 0, 2>(*p, epi, st); break;

@@ -74,6 +74,11 @@ struct GemmDP {
     // as per-tile partials ssq_in[m][ssq_np]; the kernel folds them in index order into rstd[m] and turns the bf16 rows of nh_in it loads (row-major, ld = K)
     // into X fragments in registers: x = rnd(rnd(h * rstd) * nw).  One dependent kernel and one barrier-separated prologue less than NORM == 1.
     const float* ssq_in; int ssq_np;
+    // NORM == 3 (round 6; the NORM == 2 arithmetic for ONE m-block, M <= 16): a wave's slice of the residual rows, of the norm weight and the rows' partials are
+    // DMA'd into a wave-private LDS region with lane-dense 16-byte loads (global_load_lds: M x slice / 1 KiB instructions instead of one 64-lane load per k-block
+    // and operand — at 2 rows 3 load instructions per wave instead of 15; the vector memory pipe takes ~16 cycles per 64-lane instruction however few lanes carry
+    // data, and the issue phase of normx+wqkv measured 1.6 us: profiles/r06_lat_probe_rows2.txt), fragments are read back with ds_read_b128.  stg = bytes per wave.
+    int stg;
     // EPI_RESID: if set, the epilogue also writes ssq_out[m * ssq_ld + pair] = sum of the squares of the h values it STORES in row m over its pair of
     // row-blocks (pair = row-block / 2; row-block itself for one-row-block tiles): ssq_ld = N / 32 (N / 16)
     float* ssq_out; int ssq_ld;

@@ -103,6 +103,7 @@ __device__ inline void f32_epilogue(const GemmFP& p, const f4 (&v)[IW], int rbA,
 
 template <int I, int J, int EPI, int NX>
 __global__ __launch_bounds__(F32_WAVES * 64) void dec_gemm_f32_kernel(GemmFP p) {
+    car_kernarg_prefetch<(sizeof(GemmFP) + 63 + 48) / 64>();      // (round 6) every line of the argument block requested at once instead of one scalar-cache miss per first use
     extern __shared__ __attribute__((aligned(16))) float red_all[];   // [8 waves][I*J][64] f4 (+ NX: [8 waves][J][16] slice sums of squares)
     if (p.w_nt & 2) __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
@@ -222,6 +223,7 @@ template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt v
 
 template <int WN, int WM, int KG, int SK, int NST, int EPI, int NX>
 __global__ __launch_bounds__(WN * WM * KG * 64, (WN * WM * KG == 4 ? 3 : (KG == 1 ? 2 : 4))) void dec_gemm_f32t_kernel(GemmFP p) {
+    car_kernarg_prefetch<(sizeof(GemmFP) + 63 + 48) / 64>();      // (round 6) every line of the argument block requested at once instead of one scalar-cache miss per first use
     extern __shared__ __attribute__((aligned(16))) float ring_all[];
     if (p.w_nt & 2) __builtin_amdgcn_s_setprio(3);
     constexpr int NW = WN * WM, RBW = 2 * WN, MBW = 2 * WM, CHK = RBW + MBW, CH = CHK * SK, SLG = 8 / KG;
@@ -510,6 +512,7 @@ extern "C" int car_pick_gemm_f32_cfg(int M, int N, int K, int epi) { return car_
 #define AF_UNR 2
 #endif
 __global__ __launch_bounds__(256) void dec_attn_f32_kernel(AttnFP p) {
+    car_kernarg_prefetch<(sizeof(AttnFP) + 63 + 48) / 64>();      // (round 6) every line of the argument block requested at once instead of one scalar-cache miss per first use
     __shared__ float red[4][4][66];           // per wave, per row group: m, l, o[64]
     const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
     const int pos = *p.pos;
@@ -592,6 +595,7 @@ __global__ __launch_bounds__(64) void dec_attn_f32_combine_kernel(AttnFP p) {
 // w2 of the other chain "ran" 169 us beside a 181-us attention and finished with its tail).  Same bytes in flight per CU as 4-wave workgroups at 6 per CU.
 template <int NI>
 __global__ __launch_bounds__(256 * NI) void dec_attn_f32_fused_kernel(AttnFP p, int n_items) {
+    car_kernarg_prefetch<(sizeof(AttnFP) + 63 + 48) / 64>();      // (round 6) every line of the argument block requested at once instead of one scalar-cache miss per first use
     extern __shared__ float occupancy_pad[];  // never touched: the launcher sizes it to cap the workgroups per CU (form 4)
     __shared__ float red[NI][4][4][66];       // per item: per wave, per row group: m, l, o[64]
     __shared__ float spl[NI][8][66];          // per item, per split: m, l, o[64]

@@ -633,7 +633,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
                  (const void*)forced_tokens, (void*)logits_out);
         { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
-                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0) + (CAR_KNOB("CAR_NO_RUNAHEAD") ? 4 : 0)));
+                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0) + (CAR_KNOB("CAR_NO_RUNAHEAD") ? 4 : 0) + (CAR_KNOB("CAR_NO_STAGED_NORMX") ? 8 : 0)));
           strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         { const char* k1 = CAR_KNOB("CAR_ATTN_F32_FORM"); const char* k2 = CAR_KNOB("CAR_LINEAR_PRIO"); const char* k3 = CAR_KNOB("CAR_NORMX_MAX"); const char* k4 = CAR_KNOB("CAR_NORMX_J4"); char kb3[64]; snprintf(kb3, sizeof(kb3), "|x%s|%s|%s|%s", k1 ? k1 : "-", k2 ? k2 : "-", k3 ? k3 : "-", k4 ? k4 : "-"); strncat(keyb, kb3, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);

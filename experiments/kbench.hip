@@ -290,7 +290,17 @@ static void test_gemm_normx() {
             CK(hipDeviceSynchronize());
             auto o = d2h(dO, (size_t)M * N);
             double e = 0; for (size_t i = 0; i < o.size(); ++i) e = std::max(e, std::fabs((double)o[i] - (double)rb((float)ref[i])));
-            char nm[96]; snprintf(nm, sizeof(nm), "dec_gemm NORM==2 (on-the-fly RMSNorm) cfg %d M=%d K=%d", cfg, M, D); report(nm, e, 0.3);      // |x| up to ~40: one bf16 ulp = 0.25
+            char nm[96]; snprintf(nm, sizeof(nm), "dec_gemm NORM==2/3 (on-the-fly RMSNorm) cfg %d M=%d K=%d", cfg, M, D); report(nm, e, 0.3);      // |x| up to ~40: one bf16 ulp = 0.25
+            if (cfg == 111 || cfg == 211 || cfg == 411) {      // these ran the staged form (NORM == 3): the register form (NORM == 2) of the same tile must give the same bits
+                float* dO2 = dalloc<float>((size_t)M * N); CK(hipMemset(dO2, 0xff, (size_t)M * N * 4));
+                GemmDP q2 = q; q2.outf = dO2;
+                if (cfg == 111) launch_gemm_ij<1, 1, 8, 0, 2>(q2, EPI_LOGITS, 0); else if (cfg == 211) launch_gemm_ij<2, 1, 8, 0, 2>(q2, EPI_LOGITS, 0); else launch_gemm_ij<4, 1, 8, 0, 2>(q2, EPI_LOGITS, 0);
+                CK(hipDeviceSynchronize());
+                auto o2 = d2h(dO2, (size_t)M * N);
+                double eb = 0; for (size_t i = 0; i < o.size(); ++i) eb = std::max(eb, std::fabs((double)o[i] - (double)o2[i]));
+                snprintf(nm, sizeof(nm), "   ... staged (NORM==3) vs register (NORM==2) form, cfg %d M=%d: bit-exact", cfg, M); report(nm, eb, 0.0);
+                CK(hipFree(dO2));
+            }
         }
         for (void* q : {(void*)dH, (void*)dWn, (void*)dW, (void*)dS, (void*)dO}) CK(hipFree(q));
     }

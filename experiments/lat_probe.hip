@@ -196,7 +196,7 @@ int main(int argc, char** argv) {
         double layer_start = prev_exit;
         for (int k = 0; k < KPL; ++k) {
             const int s = L * KPL + k; const int n = std::min(g_k[s].wgs, 2048);
-            long long first = 0, last = 0; std::vector<double> e0, ph[5], hd;
+            long long first = 0, last = 0; std::vector<double> e0, ph[5], hd, iss;
             for (int w = 0; w < n; ++w) {
                 const long long* t = &hs[((size_t)s * 2048 + w) * 8];
                 if (!t[0]) continue;
@@ -204,12 +204,14 @@ int main(int argc, char** argv) {
                 last = std::max(last, t[5] ? t[5] : t[0]);
                 if (w >= g_k[s].main) { hd.push_back((double)((t[5] ? t[5] : t[0]) - t[0]) / 100.0); continue; }      // helper: lifetime only
                 e0.push_back((double)t[0]);
+                if (t[6]) iss.push_back((double)(t[6] - t[0]) / 100.0);
                 long long prevt = t[0];
                 for (int i = 1; i <= 5; ++i) { if (t[i]) { ph[i - 1].push_back((double)(t[i] - prevt) / 100.0); prevt = t[i]; } else ph[i - 1].push_back(0.0); }
             }
             const double ramp = (med(e0) - (double)first) / 100.0;
             printf("%-34s %5d | %6.2f %6.2f | %6.2f %6.2f %6.2f %6.2f %6.2f | %6.2f\n", g_k[s].name.c_str(), g_k[s].wgs, ((double)first - prev_exit) / 100.0, ramp,
                    med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]), (double)(last - first) / 100.0);
+            if (!iss.empty()) printf("%34s       prologue loads all issued %.2f us after entry (median)\n", "", med(iss));
             if (!hd.empty()) { std::sort(hd.begin(), hd.end()); printf("%34s %5zu helper workgroups: lifetime median %.2f, max %.2f us\n", "", hd.size(), hd[hd.size() / 2], hd.back()); }
             prev_exit = (double)last;
         }

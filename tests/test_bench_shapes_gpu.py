@@ -56,7 +56,7 @@ def test_xl_two_chains_teacher_forced_at_bench_shape(B, twin):
         assert agree[gold["margin"][0] > 2.0 * float(cal["ref_bf16_max"])].all()
 
 
-@pytest.mark.parametrize("B,rows", [(288, (0, 100, 250)), (192, (0, 150))])
+@pytest.mark.parametrize("B,rows", [(288, (0, 100, 250)), (192, (0, 150)), (384, (0, 192, 300))])      # 384 = the bench shape: three chains of 128 rows (the tile pick depends on M)
 def test_xl_exact_mode_bit_identical_in_every_chain_of_the_default_schedule(B, rows):
     """The bit-identical mode at model size, in a BATCH, on the schedule the library chooses by itself (what `bench.py --precision fp32` times): 288 sequences =
     three chains of 96 rows with the early one-chain graph for the first positions, the 12-wave one-launch attention, on-the-fly RMSNorm linears on the tiled and

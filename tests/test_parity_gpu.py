@@ -636,15 +636,38 @@ def test_small_chain_runahead_and_attention_do_not_change_a_bit(B, cfg_scale, mo
     emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
     eng = Engine(cfg, "bf16", dev=True); eng.load_state_dict(gsd); eng.finalize()
     eng.encode_control(img.cuda())
-    monkeypatch.setenv("CAR_NO_RUNAHEAD", "1"); monkeypatch.setenv("CAR_ATTN_OLD_SMALL", "1")
+    monkeypatch.setenv("CAR_NO_RUNAHEAD", "1"); monkeypatch.setenv("CAR_ATTN_OLD_SMALL", "1"); monkeypatch.setenv("CAR_NO_STAGED_NORMX", "1")
     want, want_l = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=cfg_scale, return_logits=True)
     want, want_l = want.cpu(), want_l.cpu()
-    for env in ({"CAR_ATTN_OLD_SMALL": "1"}, {"CAR_NO_RUNAHEAD": "1"}, {}):
-        monkeypatch.delenv("CAR_NO_RUNAHEAD", raising=False); monkeypatch.delenv("CAR_ATTN_OLD_SMALL", raising=False)
+    for env in ({"CAR_ATTN_OLD_SMALL": "1"}, {"CAR_NO_RUNAHEAD": "1"}, {"CAR_NO_STAGED_NORMX": "1"}, {}):      # (staged on-the-fly norm, NORM == 3: the NORM == 2 arithmetic with lane-dense operand loads)
+        for k in ("CAR_NO_RUNAHEAD", "CAR_ATTN_OLD_SMALL", "CAR_NO_STAGED_NORMX"):
+            monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got, got_l = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=cfg_scale, return_logits=True)
         assert eng.stats()["graph_used"], env
         assert torch.equal(got.cpu(), want), env
         assert torch.equal(got_l.cpu(), want_l), env
+    eng.close()
+
+
+def test_two_chains_free_running_twins_agree_at_model_b():
+    """Two decode chains as parallel graph branches, FREE-RUNNING (what bench.py's twin check asserts at XL): identical inputs in row 0 (chain 0) and row B/2
+    (chain 1) must give identical tokens and logits on every call.  Round 6 found the teacher-forced comparison blind to a stale step position: a dec_gemm that
+    read *pos at kernel entry instead of in its epilogue wrote K / V rows one position early in some workgroups, and only the fed-back tokens showed it."""
+    from controlar_amd import config as C, synth
+    from controlar_amd.engine import Engine
+    cfg = C.b_t2i(256, adapter_size="small", condition_type="canny")
+    gsd, _ = synth.path_state_dicts(cfg, seed=0)
+    B, n_new = 384, 96
+    img = synth.canny_like_control(B, 256, 256); emb, mask = synth.text_embeddings(B, cfg.gpt.cls_token_num, cfg.gpt.caption_dim)
+    t = B // 2
+    img[t], emb[t], mask[t] = img[0], emb[0], mask[0]
+    eng = Engine(cfg, "bf16"); eng.load_state_dict(gsd); eng.finalize()
+    eng.encode_control(img.cuda())
+    for it in range(3):
+        toks, logits = eng.generate(emb.cuda(), n_new, mask.cuda(), cfg_scale=1.0, return_logits=True)
+        assert eng.stats()["graph_used"]
+        assert torch.equal(toks[0], toks[t]), (it, int((toks[0] != toks[t]).nonzero()[0]))
+        assert torch.equal(logits[0], logits[t]), it
     eng.close()

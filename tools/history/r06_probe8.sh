@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r06_probe8; mkdir -p $O
+timeout 300 experiments/kbench check > $O/kbench_check.txt 2>&1; tail -1 $O/kbench_check.txt; grep FAIL $O/kbench_check.txt | head; grep "staged" $O/kbench_check.txt | head -12
+L=experiments/lat_probe
+run() { local name=$1; shift; timeout 60 $L "$@" > $O/$name.txt 2>&1; }
+run rows2_nopf 2 631
+run rows2_m2 2 631 0 1 12 2 192 160
+run rows8_m2 8 631 0 1 12 2 96 160
+run rows16_nopf 16 631
+grep -H "instrumented chain" $O/*.txt
+cat $O/rows2_m2.txt | tail -26
