@@ -176,7 +176,9 @@ def test_decode_gemm_tile_choice_is_valid_for_every_model_size():
             for N, K, epi in linears:
                 cfg = pick(M, N, K, epi)
                 I, J, w8 = cfg // 100, (cfg // 10) % 10, cfg % 10
-                assert I in (1, 2, 4) and J in (1, 2, 4) and w8 in (0, 1), (dim, M, N, K, epi, cfg)
+                assert I in (1, 2, 4) and J in (1, 2, 4) and w8 in (0, 1, 2), (dim, M, N, K, epi, cfg)
+                # round 6: the one 16-wave tile (cfg 112) exists for the narrow RESID linears of a one-m-block chain only
+                assert w8 != 2 or (cfg == 112 and epi == EPI_RESID and M <= 16 and N // 16 <= 128), (dim, M, N, K, epi, cfg)
                 assert N % (16 * I) == 0 and K % 32 == 0, (dim, M, N, K, epi, cfg)
                 assert epi != EPI_SWIGLU or I >= 2, (dim, M, N, K, epi, cfg)          # the (a, c) pair needs two adjacent row-blocks in one tile
 
