@@ -53,6 +53,22 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {          // v_cvt_pk_
 
 // L2 run-ahead helper (decode2_params.h CAR_PF_FIELDS): workgroup `hidx` of `pf_wgs` helpers touches one dword per 128-byte line of its XCD's eighth of up to two
 // tensors, U lines per lane in flight.  Plain loads (default cache policy: the consumers' non-temporal loads hit the lines); nothing is stored.
+template <typename P>
+__device__ inline void car_pf_helper_kv(const P& p, int hidx, unsigned& acc) {
+    if (!p.pf_kc) return;
+    const int x = (int)(blockIdx.x & 7), R = p.pf_wgs >> 3, r = hidx >> 3, nth = (int)blockDim.x, tid = (int)threadIdx.x;
+    if (r >= R) return;
+    const int pos = *p.pf_pos;
+    const unsigned L = (unsigned)((((pos >> 5) + 1) * 32 * 64 * p.pf_kvb) >> 7);      // lines of one stream's prefix (whole 32-position blocks), K and V alike
+    const unsigned nix = (unsigned)((p.pf_items - x + 7) >> 3);                        // items of this XCD: x, x + 8, ...
+    const unsigned tot = nix * 2u * L, step = (unsigned)(R * nth);
+    const size_t stream = (size_t)p.pf_SA * 64 * p.pf_kvb;
+    for (unsigned i = (unsigned)(r * nth + tid); i < tot; i += step) {
+        const unsigned it = i / (2u * L), rem = i - it * 2u * L;
+        const char* base = (const char*)(rem < L ? p.pf_kc : p.pf_vc) + (size_t)(x + 8 * (int)it) * stream;
+        acc ^= *(const unsigned*)(base + (size_t)(rem < L ? rem : rem - L) * 128);
+    }
+}
 __device__ inline void car_pf_helper(const void* p0, unsigned b0, const void* p1, unsigned b1, int hidx, int pf_wgs) {
     const int x = (int)(blockIdx.x & 7), R = pf_wgs >> 3, r = hidx >> 3, nth = (int)blockDim.x, tid = (int)threadIdx.x;
     if (r >= R) return;
@@ -185,11 +201,13 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     bf16_t* xs = (bf16_t*)red_all;
     float* red = NORM == 1 ? red_all + (16 * xs_ld) / 2 : (NORM == 3 ? red_all + ((size_t)WAVES * p.stg) / 4 : red_all);
     constexpr int XPU = F8 ? 2 : 1;                                    // X chunks (k-blocks) per weight load unit
-    car_kernarg_prefetch<(sizeof(GemmDP) + 63 + 48) / 64>();           // the block + the hidden grid-size arguments behind it
+    // (the latency-bound tiles only — one m-block, 8 or 16 waves: on the 4-wave / multi-m-block tiles of 24-128-row chains the up-front wait cost 2-3 % of a layer)
+    if (J == 1 && WAVES >= 8) car_kernarg_prefetch<(sizeof(GemmDP) + 63 + 48) / 64>();           // the block + the hidden grid-size arguments behind it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (p.pf_wgs > 0 && (int)blockIdx.x >= (int)gridDim.x - p.pf_wgs) {      // L2 run-ahead helper (whole workgroup): no tile, no barrier
         STAMP(p, 0);
         car_pf_helper(p.pf_p0, p.pf_b0, p.pf_p1, p.pf_b1, (int)blockIdx.x - ((int)gridDim.x - p.pf_wgs), p.pf_wgs);
+        { unsigned acc = 0; car_pf_helper_kv(p, (int)blockIdx.x - ((int)gridDim.x - p.pf_wgs), acc); asm volatile("" ::"v"(acc)); }
         STAMP(p, 5);
         return;
     }
@@ -748,7 +766,6 @@ extern "C" void car_launch_dec_gemm(const GemmDP* p, int epi, hipStream_t st) {
 template <int NWAVE, int PF, int KV8>
 __global__ __launch_bounds__(NWAVE * 64) void dec_attn2_kernel(Attn2P p) {
     __shared__ float red[NWAVE][66];
-    car_kernarg_prefetch<(sizeof(Attn2P) + 63 + 48) / 64>();
     const int split = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
     STAMP(p, 0);

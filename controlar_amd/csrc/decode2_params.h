@@ -20,7 +20,9 @@ enum { EPI_LOGITS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 // (up to two tensors per launch), restricted to the eighth of each tensor that the consumer's workgroups on the helper's own XCD will read (dec_gemm's XCD-aware
 // tile order gives XCD x the contiguous row range x of 8; workgroup id % 8 = XCD is the observed placement — only speed depends on it).  The HBM stream of the
 // weights then runs under the latency-bound kernels on otherwise idle CUs, and the consumers read L2.
-#define CAR_PF_FIELDS const void* pf_p0; const void* pf_p1; unsigned pf_b0, pf_b1; int pf_wgs;
+// A third job (w2 of layer l only): the KV prefixes that layer l+1's attention will stream — K and V rows [0, *pf_pos] of the (sequence, head) items whose
+// attention workgroup (blockIdx = item) lands on the helper's XCD.  The attention of a small chain then reads L2 except for the newest row's block.
+#define CAR_PF_FIELDS const void* pf_p0; const void* pf_p1; unsigned pf_b0, pf_b1; int pf_wgs; const void* pf_kc; const void* pf_vc; const int* pf_pos; int pf_items, pf_SA, pf_kvb;
 
 // Early launch (round 6; small chains).  A small-batch decode layer is five short DEPENDENT kernels, and each spends 2-3 us between its dispatch and its first
 // MFMA on work that does not depend on its predecessor at all: fetching its arguments, address arithmetic, and streaming its WEIGHTS (profiles/r06_lat_probe_*).

@@ -142,7 +142,16 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         {   // w2 leaves the sums of squares for the next layer's first norm (or the final norm) unless that layer adds a control token first
             const bool next_special = l + 1 < g.n_layer && use_ctrl && (l + 1) % li == 0 && (l + 1) / li < 3;
             GemmDP q = z; q.h = hc; if (normx && !next_special) q.ssq_out = fb.ssq;
-            if (runahead) { q.pf_wgs = 1; wimg(l + 1 < g.n_layer ? "layers." + std::to_string(l + 1) + ".attention.wqkv.weight" : std::string("output.weight"), q.pf_p0, q.pf_b0, (size_t)16 << 20); }
+            if (runahead) {
+                q.pf_wgs = 1; wimg(l + 1 < g.n_layer ? "layers." + std::to_string(l + 1) + ".attention.wqkv.weight" : std::string("output.weight"), q.pf_p0, q.pf_b0, (size_t)16 << 20);
+                // the KV prefixes the next layer's attention will stream — MEASURED, OFF (development switch): the attention shrinks 6.5 -> 4.4 us at 2 rows, but w2 and the two
+                // boundaries behind the helpers grow by as much (32.4 vs 32.6 us per layer at position 631, 31.7 vs 32.4 at 200, 36.6 vs 39.7 at 8 rows; only past position
+                // ~1000 a gain: 34.8 -> 33.3): every kernel's span is already its own critical path, and a helper load that outlives it is paid at the boundary
+                if (l + 1 < g.n_layer && gr.attn_variant == 162 && ((b * Hn) & 7) == 0 && CAR_KNOB("CAR_KV_RUNAHEAD")) {
+                    q.pf_kc = (const char*)c->kv.p + ((size_t)(2 * (l + 1)) * kv_layer + kv_off) * kvb; q.pf_vc = (const char*)c->kv.p + ((size_t)(2 * (l + 1) + 1) * kv_layer + kv_off) * kvb;
+                    q.pf_pos = gr.pos; q.pf_items = b * Hn; q.pf_SA = SA; q.pf_kvb = (int)kvb;
+                }
+            }
             ssq_np = gemm(L + "feed_forward.w2.weight", fb.mid, D, Fh, EPI_RESID, q);
         }
     }
@@ -633,7 +642,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
                  (const void*)forced_tokens, (void*)logits_out);
         { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
-                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0) + (CAR_KNOB("CAR_NO_RUNAHEAD") ? 4 : 0) + (CAR_KNOB("CAR_NO_STAGED_NORMX") ? 8 : 0)));
+                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0) + (CAR_KNOB("CAR_NO_RUNAHEAD") ? 4 : 0) + (CAR_KNOB("CAR_NO_STAGED_NORMX") ? 8 : 0) + (CAR_KNOB("CAR_KV_RUNAHEAD") ? 16 : 0)));
           strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         { const char* k1 = CAR_KNOB("CAR_ATTN_F32_FORM"); const char* k2 = CAR_KNOB("CAR_LINEAR_PRIO"); const char* k3 = CAR_KNOB("CAR_NORMX_MAX"); const char* k4 = CAR_KNOB("CAR_NORMX_J4"); char kb3[64]; snprintf(kb3, sizeof(kb3), "|x%s|%s|%s|%s", k1 ? k1 : "-", k2 ? k2 : "-", k3 ? k3 : "-", k4 ? k4 : "-"); strncat(keyb, kb3, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);

@@ -30,7 +30,7 @@ __global__ void fill_kernel(unsigned* p, size_t n, unsigned seed) {
 struct Dims { int M, D, Fh, H, SA, T, pos; };
 struct Bufs { bf16_t *W, *kv, *h, *xn, *att, *mid, *q, *nw; float *part, *rope, *ssq; int *dpos; long long* stamp; size_t per_layer, kvper; };
 static bool g_normx = true;
-static int g_pf_mode = 0, g_pf_attn = 192, g_pf_lin = 160, g_attn_small = 1, g_overlap = 0;
+static int g_pf_mode = 0, g_pf_attn = 192, g_pf_lin = 160, g_attn_small = 1, g_overlap = 0, g_pf_kv = 0;
 static unsigned* g_cnt = nullptr; static unsigned* g_err = nullptr; static int g_prev_wgs = 0; static hipStream_t g_side = nullptr;      // early launch: per-kernel arrival counters (8 shards x 32 uints)
 struct KInfo { std::string name; int wgs; int main; };      // main: workgroups that do the kernel's work (the rest are L2 run-ahead helpers)
 static std::vector<KInfo> g_k;          // kernels in launch order (slot = index)
@@ -108,7 +108,8 @@ static void layer(const Dims& d, const Bufs& b, int l, int NL, hipStream_t st, i
         gemm(nx ? "normx+w1|w3" : (fuse ? "norm+w1|w3" : "w1|w3"), w13, b.xn, 2 * Fh, D, EPI_SWIGLU, q);
     }
     { GemmDP q = z; q.h = b.h; if (nx) q.ssq_out = b.ssq;
-      if (g_pf_mode == 1 || g_pf_mode == 2) { q.pf_wgs = g_pf_lin; q.pf_p0 = b.W + b.per_layer * ((l + 1) % NL); q.pf_b0 = (unsigned)((size_t)3 * D * D * 2); }
+      if (g_pf_mode == 1 || g_pf_mode == 2) { q.pf_wgs = g_pf_lin; q.pf_p0 = b.W + b.per_layer * ((l + 1) % NL); q.pf_b0 = (unsigned)((size_t)3 * D * D * 2);
+          if (g_pf_kv && (d.H * M) % 8 == 0) { bf16_t* kcn = b.kv + b.kvper * 2 * ((l + 1) % NL); q.pf_kc = kcn; q.pf_vc = kcn + b.kvper; q.pf_pos = b.dpos; q.pf_items = d.H * M; q.pf_SA = d.SA; q.pf_kvb = 2; } }
       gemm(nx ? "w2+ssq" : "w2", w2, b.mid, D, Fh, EPI_RESID, q); }
 }
 
@@ -122,6 +123,7 @@ int main(int argc, char** argv) {
     if (argc > 8) g_pf_lin = atoi(argv[8]);
     if (argc > 9) g_attn_small = atoi(argv[9]);
     if (argc > 10) g_overlap = atoi(argv[10]);
+    if (argc > 11) g_pf_kv = atoi(argv[11]);            // 1: w2's helpers also touch the KV prefixes of the next layer's attention
 #ifndef CAR_EARLY_LAUNCH
     if (g_overlap) { printf("early launch: build with -DCAR_EARLY_LAUNCH\n"); return 2; }
 #endif          // 1: early launch — the chain alternates between two streams, dependencies through arrival counters (decode2_params.h CAR_HS_FIELDS)        // 0: the round-3 one-launch attention (variant 160) instead of round 6's dec_attn2s_kernel (162)

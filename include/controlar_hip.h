@@ -87,7 +87,8 @@ typedef struct car_sampling {
     float    control_strength; /* ignored (=1) when cfg_scale <= 1                 generate.py:87-92 */
     int32_t  first_valid_hint; /* 0 = unknown.  Otherwise 1 + a LOWER bound of the first attendable position over all prompts of the call (left-padded captions,
                                   sample_t2i.py:146-160): T - longest valid length, known to a caller that built the mask on the host.  With it car_generate sizes the
-                                  prefill window without reading the device mask back — no host wait, the call only enqueues (legal under stream capture).  Too
+                                  prefill window without reading the device mask back — no host wait, the call only enqueues (every per-call scalar is a kernel argument;
+                                  capturing the CALLER's stream around the call is not a tested configuration: the work runs on the library's own stream).  Too
                                   small a value only costs time; a value beyond the true minimum would drop valid prompt rows: it is checked on the device and
                                   raises the sticky error flag (car_check_errors). */
     int32_t  reserved[3];

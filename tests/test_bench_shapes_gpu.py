@@ -116,7 +116,7 @@ def test_xl_base_depth_cfg4_b64_vs_oracle_steps():
     eng.close()
 
 
-@pytest.mark.parametrize("prec,B,atol,mtol", [("bf16", 33, 0.24, 0.018), ("fp32", 17, 2e-3, 1e-4)])      # bf16: 1.5 x measured (0.13-0.16 / 0.012, profiles/r05_parity_measured.jsonl)
+@pytest.mark.parametrize("prec,B,atol,mtol", [("bf16", 33, 0.32, 0.024), ("fp32", 17, 2e-3, 1e-4)])      # bf16: 2 x measured (0.13-0.16 / 0.012, profiles/r05_parity_measured.jsonl; ADVICE r5: 1.5 x one measurement is flaky across compiler updates)
 def test_vq16_real_512_in_batch_chunks(prec, B, atol, mtol):
     """32x32 tokens -> 512x512 pixels through the real VQ-16 decoder; B is one more than the activation-chunk size
     (engine_vq.hip car_vq_decode: 32 images in bf16, 15-16 in fp32), the golden tokens sit in the first and the last chunk."""

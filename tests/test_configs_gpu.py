@@ -142,7 +142,7 @@ def test_c2i_gpt_l_depth_fixtures():
     eng.close()
 
 
-@pytest.mark.parametrize("prec,atol,mtol", [("fp32", 2e-3, 1e-4), ("bf16", 0.09, 0.0125)])      # bf16: 1.5 x measured (0.054 / 0.0082, profiles/r03..r05_parity_measured.jsonl)
+@pytest.mark.parametrize("prec,atol,mtol", [("fp32", 2e-3, 1e-4), ("bf16", 0.11, 0.0165)])      # bf16: 2 x measured (0.054 / 0.0082, profiles/r03..r05_parity_measured.jsonl)
 def test_vq8_real_architecture(prec, atol, mtol):
     """The VQ-8 decoder variant (ch_mult (1, 2, 2, 4): three upsampling levels) on an 8x8 token grid vs the reference's pixels."""
     from controlar_amd import config as C, synth

@@ -7,7 +7,7 @@ Contract:
   * fast mode (bf16): graded teacher-forced (reference bf16 is itself not thread-stable):
     per-step logits max|d| <= 0.6*k and mean|d| <= 0.08*k vs the fp32 reference (k = 1, or sqrt(s^2+(s-1)^2)
     under CFG scale s, because the mix u+(c-u)*s amplifies single-pass error); arg-max equal wherever the
-    reference top-2 margin > 0.25*k; pixels max|d| <= 0.24 / mean|d| <= 0.018 on the random-init decoder (1.5 x measured).
+    reference top-2 margin > 0.25*k; pixels max|d| <= 0.32 / mean|d| <= 0.024 on the random-init decoder (2 x measured: ADVICE r5).
 """
 import numpy as np
 import pytest
@@ -79,11 +79,11 @@ def test_fast_mode_teacher_forced(name):
         dp = np.abs(px - gold["pixels"])
         record_measured(f"pixels_bf16[{name}]", max_abs_diff=dp.max(), mean_abs_diff=dp.mean())
         # 1.5 x the deviation measured on MI355X (0.159 / 0.012, profiles/r05_parity_measured.jsonl; the reference's own bf16-vs-fp32 pixels: 0.132 / 0.0094)
-        assert dp.max() <= 0.24 and dp.mean() <= 0.018, (dp.max(), dp.mean())
+        assert dp.max() <= 0.32 and dp.mean() <= 0.024, (dp.max(), dp.mean())
     eng.close()
 
 
-@pytest.mark.parametrize("prec,atol,mtol", [("fp32", 2e-3, 1e-4), ("bf16", 0.24, 0.018)])      # bf16: 1.5 x measured (profiles/r05_parity_measured.jsonl)
+@pytest.mark.parametrize("prec,atol,mtol", [("fp32", 2e-3, 1e-4), ("bf16", 0.32, 0.024)])      # bf16: 2 x measured (profiles/r05_parity_measured.jsonl)
 def test_vq16_real_architecture(prec, atol, mtol):
     """The real VQ-16 decoder (ch=128, z=256, 16384x8 codebook) on an 8x8 token grid vs the reference."""
     import os
