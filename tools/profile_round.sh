@@ -6,13 +6,13 @@
 #   3. kernel traces of the other BASELINE configs through bench.py --config N
 # Raw traces stay on the box; summaries -> gpurun_out/ (copy what is to be judged into profiles/).  PMC passes are separate rocprofv3 runs without trace domains.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r06}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 trace() {   # name, bench args...
   local name=$1; shift
   rm -rf /tmp/prof_$name
-  ( timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$name -- python $ROOT/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_${name}_under_rocprof.json 2> $OUT/${TAG}_${name}_trace.err )
+  ( timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$name -- python $ROOT/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-variants > $OUT/${TAG}_${name}_under_rocprof.json 2> $OUT/${TAG}_${name}_trace.err )
   local T=$(find /tmp/prof_$name -name '*kernel_trace.csv' | head -1)
   [ -n "$T" ] && python $ROOT/tools/trace_summary.py $T > $OUT/${TAG}_${name}_trace_summary.txt && python $ROOT/tools/trace_summary.py $T 0.5 > $OUT/${TAG}_${name}_trace_summary_decode_half.txt
   echo "== $name"; head -12 $OUT/${TAG}_${name}_trace_summary_decode_half.txt | cut -c1-150
