@@ -1225,6 +1225,12 @@ extern "C" void car_launch_prefill_rope_kv2(void* qkv, void* kc, void* vc, const
 template <int NQ>
 __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
     car_kernarg_prefetch<(sizeof(Norm2P) + 63 + 48) / 64>();
+    if (p.pf_wgs > 0 && (int)blockIdx.x >= (int)gridDim.x - p.pf_wgs) {      // L2 run-ahead helper (whole workgroup; this kernel has no barrier)
+        STAMP(p, 0);
+        car_pf_helper(p.pf_p0, p.pf_b0, p.pf_p1, p.pf_b1, (int)blockIdx.x - ((int)gridDim.x - p.pf_wgs), p.pf_wgs);
+        STAMP(p, 5);
+        return;
+    }
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     STAMP(p, 0);
     const bool hs_fresh = HS_FRESH(p), hs_wt = HS_WT(p);
@@ -1285,8 +1291,11 @@ __global__ __launch_bounds__(256) void rmsnorm2_kernel(Norm2P p, int rows) {
 }
 extern "C" void car_launch_rmsnorm2(const Norm2P* p, long rows, hipStream_t st) {
     const int nq = (p->D / 4 + 63) / 64;                      // column groups per lane (D <= 4096: every LlamaGen size)
-    const dim3 g((unsigned)((rows + 3) / 4)), b(256);
-    if (nq <= 4) hipLaunchKernelGGL((rmsnorm2_kernel<4>), g, b, 0, st, *p, (int)rows);
-    else if (nq <= 8) hipLaunchKernelGGL((rmsnorm2_kernel<8>), g, b, 0, st, *p, (int)rows);
-    else hipLaunchKernelGGL((rmsnorm2_kernel<16>), g, b, 0, st, *p, (int)rows);
+    Norm2P q = *p;
+    const unsigned main_wgs = (unsigned)((rows + 3) / 4);
+    if (q.pf_wgs < 0 || (main_wgs & 7)) q.pf_wgs = 0;         // the helper's XCD arithmetic assumes the main grid is a multiple of 8
+    const dim3 g(main_wgs + (unsigned)q.pf_wgs), b(256);
+    if (nq <= 4) hipLaunchKernelGGL((rmsnorm2_kernel<4>), g, b, 0, st, q, (int)rows);
+    else if (nq <= 8) hipLaunchKernelGGL((rmsnorm2_kernel<8>), g, b, 0, st, q, (int)rows);
+    else hipLaunchKernelGGL((rmsnorm2_kernel<16>), g, b, 0, st, q, (int)rows);
 }

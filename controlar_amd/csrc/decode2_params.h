@@ -111,6 +111,7 @@ struct Norm2P {
     const bf16_t* h_in; const bf16_t* emb; const int* idx; bf16_t* h_out; bf16_t* xn; const bf16_t* w;
     const bf16_t* ctrl; const int* pos; int add /* bit 0: add the control token, bit 1: raised wave priority */; int T; int n_tok; float cs;
     int D; float eps;
+    CAR_PF_FIELDS               // mid chains (17-191 rows, one chain): the 4-32 workgroups of a norm leave the chip idle — its helpers touch the weights of the linears that follow
     CAR_HS_FIELDS
     CAR_STAMP_FIELDS
 };

@@ -41,11 +41,23 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         if (it == c->w.end()) { ptr = nullptr; bytes = 0; return; }
         ptr = it->second.p; bytes = (unsigned)std::min(it->second.bytes, cap);
     };
+    // chains of 17-48 rows (on-the-fly norm: no rmsnorm2 launches to ride on): wo (80-240 workgroups) hosts w1|w3 + w2, w2 hosts the next layer's wqkv
+    const bool runahead_nx = b > 16 && b <= normx_max && b == b_total && c->n_cu >= 128 && !CAR_KNOB("CAR_NO_RUNAHEAD");
     auto helpers_for = [&](int main_wgs) -> int {      // helper workgroups beside `main_wgs` workgroups: fill the chip once, multiple of 8 (the helper's XCD arithmetic), at least 32
-        if (!runahead || (main_wgs & 7)) return 0;
+        if (!(runahead || runahead_nx) || (main_wgs & 7)) return 0;
         int h = ((c->n_cu - main_wgs) / 8) * 8;
         if (h > 192) h = 192;
         return h >= 32 ? h : 0;
+    };
+    // Mid chains (17-191 rows as ONE chain: BASELINE config 3): the rmsnorm2 launches in front of wqkv / w1|w3 / output are 4-48 workgroups on a 256-CU chip; their
+    // helpers pull the weights of the linears behind them into the XCDs' L2s (attention_norm -> wqkv; ffn_norm -> w1|w3 + w2; final norm -> 16 MB of the vocabulary projection)
+    const bool runahead_mid = b > 16 && b == b_total && c->n_cu >= 128 && !CAR_KNOB("CAR_NO_RUNAHEAD");
+    auto norm_helpers = [&](Norm2P& np, const std::string& w0, const std::string& w1, size_t cap0 = (size_t)24 << 20) {
+        if (!runahead_mid) return;
+        const int main_wgs = (b + 3) / 4;
+        if (main_wgs & 7) return;
+        int h = ((c->n_cu - main_wgs) / 8) * 8; if (h > 192) h = 192; if (h < 32) return;
+        np.pf_wgs = h; wimg(w0, np.pf_p0, np.pf_b0, cap0); if (!w1.empty()) wimg(w1, np.pf_p1, np.pf_b1);
     };
     // returns the number of sum-of-squares partials per row the kernel leaves in p.ssq_out (0 if it writes none)
     auto gemm = [&](const std::string& wname, const bf16_t* X, int N, int K, int epi, GemmDP gp_) -> int {
@@ -106,6 +118,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
             if (use_ctrl && l % li == 0 && l / li < 3) {
                 np.add |= 1; np.ctrl = (const bf16_t*)c->ctrl[l / li].p + (size_t)b0 * n_tok * D; np.pos = gr.pos; np.T = T; np.n_tok = n_tok; np.cs = cs; np.h_out = h;
             }
+            norm_helpers(np, L + "attention.wqkv.weight", "");
             car_launch_rmsnorm2(&np, b, st); ++nk;
         }
         {
@@ -129,11 +142,13 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         }
         { GemmDP q = z; q.h = hc; if (normx) q.ssq_out = fb.ssq;
           if (runahead) { q.pf_wgs = 1; wimg(L + "feed_forward.w2.weight", q.pf_p0, q.pf_b0); }
+          else if (runahead_nx) { q.pf_wgs = 1; wimg(L + "feed_forward.w13.weight", q.pf_p0, q.pf_b0); wimg(L + "feed_forward.w2.weight", q.pf_p1, q.pf_b1); }
           ssq_np = gemm(L + "attention.wo.weight", fb.att, D, D, EPI_RESID, q); }
         const bool nx2 = normx && ssq_np > 0;
         if (!nx2 && !fuse_norm) {
             Norm2P np; memset(&np, 0, sizeof(np));
             np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, L + "ffn_norm.weight"); np.D = D; np.eps = g.norm_eps; np.add = prio ? 2 : 0;
+            norm_helpers(np, L + "feed_forward.w13.weight", L + "feed_forward.w2.weight");
             car_launch_rmsnorm2(&np, b, st); ++nk;
         }
         { GemmDP q = z; q.outp = fb.mid;
@@ -142,7 +157,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
         {   // w2 leaves the sums of squares for the next layer's first norm (or the final norm) unless that layer adds a control token first
             const bool next_special = l + 1 < g.n_layer && use_ctrl && (l + 1) % li == 0 && (l + 1) / li < 3;
             GemmDP q = z; q.h = hc; if (normx && !next_special) q.ssq_out = fb.ssq;
-            if (runahead) {
+            if (runahead || runahead_nx) {
                 q.pf_wgs = 1; wimg(l + 1 < g.n_layer ? "layers." + std::to_string(l + 1) + ".attention.wqkv.weight" : std::string("output.weight"), q.pf_p0, q.pf_b0, (size_t)16 << 20);
                 // the KV prefixes the next layer's attention will stream — MEASURED, OFF (development switch): the attention shrinks 6.5 -> 4.4 us at 2 rows, but w2 and the two
                 // boundaries behind the helpers grow by as much (32.4 vs 32.6 us per layer at position 631, 31.7 vs 32.4 at 200, 36.6 vs 39.7 at 8 rows; only past position
@@ -159,6 +174,7 @@ static int enqueue_decode_step_fast(car_ctx* c, const StepBufs& sb, const Grp& g
     if (!nx3 && !fuse_norm) {
         Norm2P np; memset(&np, 0, sizeof(np));
         np.h_in = h; np.xn = fb.xn; np.w = (const bf16_t*)Wp(c, "norm.weight"); np.D = D; np.eps = g.norm_eps; np.add = prio ? 2 : 0;
+        norm_helpers(np, "output.weight", "", (size_t)16 << 20);
         car_launch_rmsnorm2(&np, b, st); ++nk;
     }
     { GemmDP q = z; q.outf = fb.logits;

@@ -622,7 +622,7 @@ def test_chain_schedule_knobs_do_not_change_tokens(chains, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("B,cfg_scale", [(1, 4.0), (8, 1.0), (3, 1.0)])
+@pytest.mark.parametrize("B,cfg_scale", [(1, 4.0), (8, 1.0), (3, 1.0), (64, 1.0), (32, 4.0), (24, 1.0), (48, 1.0)])      # 64 rows: the mid-chain form (helpers ride on the rmsnorm2 launches)
 def test_small_chain_runahead_and_attention_do_not_change_a_bit(B, cfg_scale, monkeypatch):
     """Round 6, chains of one m-block (BASELINE configs 2, 4, 5): the L2 run-ahead helper workgroups only READ weights, and the two-blocks-in-flight attention
     (dec_attn2s_kernel) keeps dec_attn2_kernel<16>'s block -> wave assignment and merge order — tokens AND logits must equal the round-5 schedule's bit for bit
