@@ -79,7 +79,7 @@ def parse():
     ap.add_argument("--config-legs", default="2,3,5,4,1",
                     help="headline configuration on one GPU only: after the exact leg, time these BASELINE configs (`--config N`, 1 warm-up + --config-leg-steps steps each) in child "
                          "processes and report them as the `configs` block of the same JSON line, so that the driver's record carries every BASELINE config, not only the headline.  '' = skip")
-    ap.add_argument("--config-leg-steps", type=int, default=2)
+    ap.add_argument("--config-leg-steps", type=int, default=3)
     ap.add_argument("--legs-budget-s", type=float, default=420.0, help="stop starting further config legs once this much wall clock has gone into them")
     ap.add_argument("--pack-cache", action="store_true",
                     help="N = 1: restore the packed weight images from the bench cache directory if this exact configuration was exported there (by the headline run of the same "
