@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from controlar_amd import config as C, synth
 from controlar_amd.engine import Engine
+from controlar_amd import _lib
+if os.environ.get('AB_LIB'): _lib.DEV_LIB_PATH = os.environ['AB_LIB']      # an experimental build of the development library
 
 B = int(sys.argv[1]); cfg_scale = float(sys.argv[2]); n_new = int(sys.argv[3])
 sets = [dict(kv.split("=") for kv in s.split(",") if kv) for s in sys.argv[4].split(";")]
