@@ -552,7 +552,10 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
             // a handful of sequences (<= 240 (sequence, head) pairs = 12 XL sequences): ONE launch of 16-wave workgroups instead of split-KV + combine —
             // one dependent kernel less per layer.  tools/small_ab.py on MI355X (XL, 1024 tokens, ms per step, same process): 2 rows 1.548 -> 1.406,
             // 8 rows 1.611 -> 1.465, 12 rows 1.887 -> 1.725; at 16 rows the split form wins again (1.890 vs 1.923)  [profiles/r03_small_ab.txt]
-            const bool one_launch = (long)bg * Hn <= 240 && !CAR_KNOB("CAR_ATTN_SPLIT_SMALL");
+            // (round 6: with dec_attn2s — two blocks in flight per wave — the one-launch form wins up to 24 XL sequences: 38.8 -> 38.1 us per layer at 16 rows, 47.5 -> 45.9 at 20,
+            //  48.4 -> 46.9 at 24, tools/mid_ab.py with CAR_ONE_LAUNCH_MAX; 480 sixteen-wave workgroups still fit the chip in one round)
+            int one_max = T <= 512 ? 480 : 240; { const char* ev = CAR_KNOB("CAR_ONE_LAUNCH_MAX"); if (ev) one_max = atoi(ev); }
+            const bool one_launch = (long)bg * Hn <= one_max && !CAR_KNOB("CAR_ATTN_SPLIT_SMALL");
             if (one_launch) gr.nsplit = 1;
             { const char* ev = CAR_KNOB("CAR_ATTN_NSPLIT"); if (ev) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) gr.nsplit = v; } }   // A/B knob: shorter attention workgroups
             // attention variant (decode2.hip; profiles/r02_kbench_*): 4 waves per (sequence, head) from 128 sequences up, 2 below; 16 in the one-launch small form
@@ -658,7 +661,7 @@ static int generate_impl(car_ctx* c, const void* text_emb, int32_t text_dtype, c
                  c->ctrl[0].p, c->maskb.p, c->dec_parts.p ? c->dec_parts.p : c->ws[10].p, (double)cs, (double)sp->cfg_scale, sp->cfg_interval, NG, emb_mask ? 1 : 0,
                  (const void*)forced_tokens, (void*)logits_out);
         { char kb2[240]; snprintf(kb2, sizeof(kb2), "|%d|gen%llu|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d", sp->sample_logits, g_alloc_gen, xn, att, mid, c->scal.p, grp[0].attn_variant, grp[0].attn_lds_pad,
-                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0) + (CAR_KNOB("CAR_NO_RUNAHEAD") ? 4 : 0) + (CAR_KNOB("CAR_NO_STAGED_NORMX") ? 8 : 0) + (CAR_KNOB("CAR_KV_RUNAHEAD") ? 16 : 0)));
+                                  grp[0].nsplit, phase, lin_prio, grp[0].attn_pgrid + 100000 * ((CAR_KNOB("CAR_NO_NORMX") ? 1 : 0) + (CAR_KNOB("CAR_NO_SMALL_FUSE") ? 2 : 0) + (CAR_KNOB("CAR_NO_RUNAHEAD") ? 4 : 0) + (CAR_KNOB("CAR_NO_STAGED_NORMX") ? 8 : 0) + (CAR_KNOB("CAR_KV_RUNAHEAD") ? 16 : 0)) + 1000000 * (CAR_KNOB("CAR_ONE_LAUNCH_MAX") ? atoi(CAR_KNOB("CAR_ONE_LAUNCH_MAX")) : 0));
           strncat(keyb, kb2, sizeof(keyb) - strlen(keyb) - 1); }
         { const char* k1 = CAR_KNOB("CAR_ATTN_F32_FORM"); const char* k2 = CAR_KNOB("CAR_LINEAR_PRIO"); const char* k3 = CAR_KNOB("CAR_NORMX_MAX"); const char* k4 = CAR_KNOB("CAR_NORMX_J4"); char kb3[64]; snprintf(kb3, sizeof(kb3), "|x%s|%s|%s|%s", k1 ? k1 : "-", k2 ? k2 : "-", k3 ? k3 : "-", k4 ? k4 : "-"); strncat(keyb, kb3, sizeof(keyb) - strlen(keyb) - 1); }
         const std::string key(keyb);
