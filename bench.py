@@ -233,6 +233,16 @@ def pack_cache_dir():
         return d2
 
 
+def config_legs(args, world):
+    """The BASELINE configs timed as child legs behind the headline: only for the default headline run on ONE GPU (a multi-GPU run times the metric, nothing else:
+    every rank would otherwise spawn its own children on its own device while the others wait at the barrier)."""
+    if world != 1 or args.no_variants or args.config != 0 or args.precision != "bf16" or args.model != "xl" or args.batch != 768:
+        return []
+    if args.weights_fp8 or args.kv_fp8 or args.sample_logits:
+        return []
+    return [int(x) for x in args.config_legs.split(",") if x.strip()]
+
+
 def child_leg(extra, timeout=900):
     """One more bench configuration in a child process (its own HIP contexts: the parent has released its device memory), returns its parsed JSON line or an error."""
     import subprocess
@@ -320,8 +330,7 @@ def main():
     def import_packed():
         for e_, f_ in ((eng, pk[0]), (vq_eng, pk[1])):
             e_._check(e_.lib.car_import_packed(e_._h, f_.encode()), "car_import_packed")
-    legs = [int(x) for x in args.config_legs.split(",") if x.strip()] if (world == 1 and not args.no_variants and args.config == 0 and args.precision == "bf16" and args.model == "xl"
-                                                                        and args.batch == 768 and not args.weights_fp8 and not args.kv_fp8 and not args.sample_logits) else []
+    legs = config_legs(args, world)
     if world == 1 and (args.pack_cache or legs):
         # one GPU: a config leg restores the images the headline run exported (same model, same build); the headline exports when legs will follow
         how = None

@@ -66,6 +66,8 @@ def test_bench_config_presets(monkeypatch):
     a = args("--config", "5"); assert (a.batch, a.fp8_mfma, a.weights_fp8, a.adapter_size) == (8, True, True, "base")        # BASELINE configs[4] as named: W8A8 on the fp8 MFMA
     a = args("--config", "5", "--fp8-weight-only"); assert (a.batch, a.fp8_mfma, a.weights_fp8) == (8, False, True)          # the weight-only variant (reported beside it)
     assert args().exact_leg_steps == 3 and not args().no_variants                                                            # the default run times the bit-identical mode too
+    assert bench.config_legs(args(), 1) == [2, 3, 5, 4, 1] and bench.config_legs(args(), 8) == []                          # ... on one GPU only: at N > 1 no rank spawns child legs
+    assert bench.config_legs(args("--config", "2"), 1) == [] and bench.config_legs(args("--no-variants"), 1) == [] and bench.config_legs(args("--precision", "fp32"), 1) == []
     assert args().config_legs == "2,3,5,4,1" and not args().pack_cache                                                       # ... and every other BASELINE config (round 6: the `configs` block)
     a = args("--gpus", "8", "--steps", "20", "--warmup", "5"); assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
     a = args("--precision", "fp32"); assert (a.batch, a.vq_precision) == (384, "bf16")          # the tokens-exact configuration: fp32 KV of 384 sequences = 162 GB, bf16 pixels
