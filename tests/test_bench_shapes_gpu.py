@@ -56,10 +56,10 @@ def test_xl_two_chains_teacher_forced_at_bench_shape(B, twin):
         assert agree[gold["margin"][0] > 2.0 * float(cal["ref_bf16_max"])].all()
 
 
-@pytest.mark.parametrize("B,rows", [(288, (0, 100, 250)), (192, (0, 150)), (384, (0, 192, 300))])      # 384 = the bench shape: three chains of 128 rows (the tile pick depends on M)
+@pytest.mark.parametrize("B,rows", [(192, (0, 150)), (384, (0, 192, 300))])      # 384 = the bench shape: three chains of 128 rows (the tile pick depends on M); round 5's 288-sequence case (three chains of 96) made way for it to keep the suite's run time
 def test_xl_exact_mode_bit_identical_in_every_chain_of_the_default_schedule(B, rows):
-    """The bit-identical mode at model size, in a BATCH, on the schedule the library chooses by itself (what `bench.py --precision fp32` times): 288 sequences =
-    three chains of 96 rows with the early one-chain graph for the first positions, the 12-wave one-launch attention, on-the-fly RMSNorm linears on the tiled and
+    """The bit-identical mode at model size, in a BATCH, on the schedule the library chooses by itself (what `bench.py --precision fp32` times): 384 sequences =
+    three chains of 128 rows with the early one-chain graph for the first positions, the 12-wave one-launch attention, on-the-fly RMSNorm linears on the tiled and
     register fp32-MFMA kernels; 192 = two chains.  The input of the reference-minted golden (fp32 CPU reference, sample_t2i.py --precision none) sits in one row of
     every chain: each must reproduce ALL 1024 reference tokens, free-running."""
     from controlar_amd import config as C, synth
