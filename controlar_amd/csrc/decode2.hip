@@ -389,9 +389,14 @@ __global__ __launch_bounds__(WAVES * 64) void dec_gemm_kernel(GemmDP p) {
     const bool epi_first = wave < IPc * J && p.M <= 16;                  // wave-uniform; one m-block chains only (the latency-bound regime: elsewhere the extra prologue instructions cost more than the round trip)
     uint2 hv_h[IWc]; float4 cs_h[IWc];
     int pos_h = 0;
-    // *pos is read up front only in one-m-block chains (a single-branch graph: every kernel completes before the next starts).  With two chains as parallel graph
-    // branches an EARLY read — even an agent-scope one served by L2 — returned the previous step's position in some workgroups (tools/twin_probe.py: twin rows in
-    // different chains diverged after 6-50 steps), while the read in the epilogue, a few microseconds later, never has: the large-batch kernels keep round 5's late read.
+    // *pos is read up front only in one-m-block chains (a single-branch graph).  With two chains as parallel graph branches every build in which the QKV epilogue
+    // took the position from a register loaded before the main loop made the chain on the SECOND branch drift (tools/twin_probe.py; swapping the row groups between
+    // the branches moves the fault with the branch).  It is NOT a stale value: instrumented builds compared the entry read (scalar and agent-scope) with the epilogue
+    // read in every epilogue unit — 0 mismatches in 1.4e8, also in runs that drifted.  The faults are lane / wave level (a few rows of one 16-row block per event; q or
+    // K units, never NaN), survive a sleep, an s_waitcnt vmcnt(0) or write-through stores in front of the epilogue stores, an opaque copy of the register and
+    // poisoned VGPRs at entry; the build with round 5's fresh load in the epilogue never shows one (0 of 192 / 384 rows over 8 x 96 steps with the same
+    // instrumentation).  Mechanism unknown (profiles/r06_posdbg_*.txt): the large-batch kernels keep the late read, and
+    // tests/test_parity_gpu.py + bench.py's twin rows guard it.
     if (EPI == EPI_QKV && p.M <= 16) pos_h = *(const __attribute__((address_space(4))) int*)(unsigned long long)p.pos;      // constant for the kernel's lifetime: through the scalar cache
     if (EPI == EPI_RESID && epi_first) {
         const int ip0 = wave / J, j0 = wave - ip0 * J;

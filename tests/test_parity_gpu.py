@@ -654,7 +654,8 @@ def test_small_chain_runahead_and_attention_do_not_change_a_bit(B, cfg_scale, mo
 def test_two_chains_free_running_twins_agree_at_model_b():
     """Two decode chains as parallel graph branches, FREE-RUNNING (what bench.py's twin check asserts at XL): identical inputs in row 0 (chain 0) and row B/2
     (chain 1) must give identical tokens and logits on every call.  Round 6 found the teacher-forced comparison blind to a stale step position: a dec_gemm that
-    read *pos at kernel entry instead of in its epilogue wrote K / V rows one position early in some workgroups, and only the fed-back tokens showed it."""
+    took *pos from a register loaded at kernel entry instead of a fresh load in its epilogue made the chain on the second graph branch drift (lane-level faults
+    in q / K units; the position VALUE was never stale: profiles/r06_posdbg_*.txt), and only the fed-back tokens showed it."""
     from controlar_amd import config as C, synth
     from controlar_amd.engine import Engine
     cfg = C.b_t2i(256, adapter_size="small", condition_type="canny")
