@@ -40,7 +40,8 @@ for it in range(int(os.environ.get("CALLS", "4"))):
     sys.stderr.flush()
     eng.lib.car_posdbg_dump()
     if it == 0:
-        for ch in range(2): eng.lib.car_posdbg_dump_adv(ch, T, T + n_new)
+        if hasattr(eng.lib, "car_posdbg_dump_adv"):
+            for ch in range(2): eng.lib.car_posdbg_dump_adv(ch, T, T + n_new)
 from collections import Counter
 ref = Counter(seen).most_common(1)[0][0]
 def fd(x): return next((i for i, (u, v) in enumerate(zip(x, ref)) if u != v), None)
